@@ -1,0 +1,133 @@
+"""CPU tests: pin the oracle (C + numpy restatements) to the golden vectors minted from the
+reference's check.py and to the reference's own known-answer cases.  No GPU needed."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle
+
+# fp32-vs-fp32 agreement with torch: scores of the peaky F6 case reach |s| ~ 60, where one fp32 ulp
+# of the score is already a 4e-6 relative change of exp(s), so F6 gets a wider band.
+TOL = {"F6": dict(rtol=2e-4, atol=2e-5)}
+DEFAULT_TOL = dict(rtol=2e-5, atol=3e-6)
+
+
+def tol(name):
+    return TOL.get(name, DEFAULT_TOL)
+
+
+def test_golden_manifest_hashes(golden):
+    for name, entry in golden.manifest.items():
+        for key, f in entry["files"].items():
+            a = golden.load(name, key)
+            assert list(a.shape) == f["shape"], (name, key)
+            assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == f["sha256"]
+
+
+@pytest.mark.parametrize("name", ["F0", "F3", "F5bf16", "F5e4m3", "F6"])
+def test_c_oracle_matches_checkpy_layout(golden, name):
+    """oracle_multi_head_attention == check.py:multi_head_attention on its own layout."""
+    H = golden.meta(name)["num_heads"]
+    Q, K, V = (golden.load(name, k) for k in "QKV")
+    out, attn = oracle.multi_head_attention(Q, K, V, H)
+    np.testing.assert_allclose(out, golden.load(name, "out"), **tol(name))
+    np.testing.assert_allclose(attn.sum(-1), 1.0, atol=1e-5)
+    if name == "F3":
+        np.testing.assert_allclose(attn, golden.load(name, "attn"), rtol=1e-5, atol=1e-7)
+    if name == "F0":
+        np.testing.assert_allclose(attn.sum(-1), golden.load(name, "attn_rowsum"), atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["F0", "F3", "F4", "F5bf16", "F6"])
+@pytest.mark.parametrize("f64", [False, True])
+def test_c_oracle_bhsd_matches_golden(golden, name, f64):
+    """The dense [B,H,S,d] entry (the layout of kernels/FlashAttention.cuh:59-63) against
+    check.py outputs mapped through check.py:14-16,24."""
+    meta = golden.meta(name)
+    H = meta["num_heads"]
+    Q, K, V = (golden.to_bhsd(golden.load(name, k), H) for k in "QKV")
+    O = oracle.attention(Q, K, V, causal=meta["causal"], f64=f64)
+    np.testing.assert_allclose(golden.to_bsd(O), golden.load(name, "out"), **tol(name))
+
+
+def test_numpy_restatement_matches_golden(golden):
+    for name in ["F0", "F3", "F6"]:
+        H = golden.meta(name)["num_heads"]
+        Q, K, V = (golden.load(name, k) for k in "QKV")
+        out, attn = oracle.mha_numpy(Q, K, V, H)
+        np.testing.assert_allclose(out, golden.load(name, "out"), **tol(name))
+    Q, K, V = (golden.to_bhsd(golden.load("F4", k), 1) for k in "QKV")
+    O = oracle.attention_numpy(Q, K, V, causal=True)
+    np.testing.assert_allclose(golden.to_bsd(O), golden.load("F4", "out"), rtol=2e-5, atol=3e-6)
+
+
+def test_known_answer_checkpy_demo(golden):
+    """check.py:30-43: all-ones (1,4,8), H=2 -> attn == 0.25, output == 1."""
+    one = golden.load("F1", "Q")
+    out, attn = oracle.multi_head_attention(one, one, one, 2)
+    np.testing.assert_allclose(out, golden.load("F1", "out"), atol=1e-6)
+    np.testing.assert_allclose(attn, golden.load("F1", "attn"), atol=1e-7)
+    np.testing.assert_allclose(out, 1.0, atol=1e-6)
+    np.testing.assert_allclose(attn, 0.25, atol=1e-7)
+
+
+def test_known_answer_maincu_all_ones(golden):
+    """tests/main.cu:24-36,107: all-ones S=16,d=16,B=H=1, scale 1/sqrt(16) -> O == 1."""
+    one = golden.load("F2", "Q")[0]          # [16,16]
+    scale = 1.0 / np.sqrt(16.0)
+    lit = oracle.attention_maincu(one, one, one, scale, causal=False)
+    np.testing.assert_allclose(lit, 1.0, atol=1e-6)
+    np.testing.assert_allclose(lit, golden.load("F2", "out")[0], atol=1e-6)
+    stable = oracle.attention(one[None, None], one[None, None], one[None, None], scale=scale)
+    np.testing.assert_allclose(stable[0, 0], lit, atol=1e-6)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_stable_form_equals_maincu_literal(causal):
+    """The max-subtracted form agrees with the reference's literal CPU check
+    (tests/main.cu:74-91) on data where raw expf does not overflow."""
+    rng = np.random.default_rng(7)
+    S, d = 48, 32
+    Q, K, V = (rng.standard_normal((S, d), dtype=np.float32) for _ in range(3))
+    scale = 1.0 / np.sqrt(d)
+    lit = oracle.attention_maincu(Q, K, V, scale, causal=causal)
+    st = oracle.attention(Q[None, None], K[None, None], V[None, None], scale=scale,
+                          causal=causal, f64=False)[0, 0]
+    np.testing.assert_allclose(st, lit, rtol=2e-5, atol=2e-6)
+
+
+def test_causal_first_row_and_isolation():
+    """Row 0 under the causal mask sees one key; heads do not leak (reference defect D2)."""
+    rng = np.random.default_rng(3)
+    Q, K, V = (rng.standard_normal((2, 3, 40, 16), dtype=np.float32) for _ in range(3))
+    O = oracle.attention(Q, K, V, causal=True)
+    np.testing.assert_allclose(O[:, :, 0], V[:, :, 0], rtol=1e-6, atol=1e-6)
+    for b in range(2):
+        for h in range(3):
+            one = oracle.attention(Q[b:b + 1, h:h + 1], K[b:b + 1, h:h + 1], V[b:b + 1, h:h + 1],
+                                   causal=True)
+            np.testing.assert_array_equal(one[0, 0], O[b, h])
+
+
+def test_rows_subset_matches_full():
+    rng = np.random.default_rng(5)
+    Q, K, V = (rng.standard_normal((1, 4, 64, 32), dtype=np.float32) for _ in range(3))
+    full = oracle.attention(Q, K, V, causal=True).reshape(4, 64, 32)
+    sub = oracle.attention_rows(Q, K, V, heads=(1, 3), rows=(10, 50), causal=True)
+    np.testing.assert_array_equal(sub, full[1:3, 10:50])
+
+
+def test_bf16_and_e4m3_rounding_match_torch(golden):
+    """Rounding helpers reproduce torch's casts (pins the low-precision INPUT semantics)."""
+    x = golden.load("F0", "Q")
+    np.testing.assert_array_equal(oracle.round_bf16(x), golden.load("F5bf16", "Q"))
+    np.testing.assert_array_equal(oracle.round_e4m3fn(x), golden.load("F5e4m3", "Q"))
+    # every e4m3fn code round-trips
+    L = oracle.lib()
+    for b in range(256):
+        v = L.oracle_e4m3fn_to_f32(b)
+        if v != v:
+            continue
+        assert L.oracle_f32_to_e4m3fn(v) == b or v == 0.0
+    assert L.oracle_f32_to_e4m3fn(1e9) == 0x7E and L.oracle_f32_to_e4m3fn(-1e9) == 0xFE
