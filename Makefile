@@ -1,0 +1,36 @@
+# Build everything for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+PKG      := flash-attention-cuda-c_amd
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     := gfx950
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC
+LIB      := $(PKG)/libflash_attention.so
+KSRC     := $(PKG)/csrc/FlashAttention.hip
+KHDR     := $(wildcard $(PKG)/csrc/*.h) $(PKG)/helpers.hpp include/flash_attention.h
+
+all: $(LIB) oracle $(PKG)/fa_main tests/fa_test
+
+$(LIB): $(KSRC) $(KHDR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KSRC)
+
+oracle:
+	$(MAKE) -s -C oracle
+
+# driver: the counterpart of the reference's main.cpp (device properties + run the configs)
+$(PKG)/fa_main: $(PKG)/main.cpp $(LIB) include/flash_attention.h
+	$(HIPCC) -O2 -std=c++17 -o $@ $(PKG)/main.cpp -L$(PKG) -lflash_attention -Wl,-rpath,'$$ORIGIN' -lpthread
+
+# test harness: the counterpart of the reference's tests/main.cu (launch + CPU check); links the oracle
+oracle/liboracle_attention.so: oracle/cpu_attention.c oracle/cpu_attention.h
+	$(MAKE) -s -C oracle
+
+tests/fa_test: tests/main.cpp $(LIB) oracle/liboracle_attention.so
+	$(HIPCC) -O2 -std=c++17 -o $@ tests/main.cpp -L$(PKG) -lflash_attention -Loracle -loracle_attention \
+	    -Wl,-rpath,'$$ORIGIN/../$(PKG)' -Wl,-rpath,'$$ORIGIN/../oracle'
+
+asm: $(KSRC) $(KHDR)
+	mkdir -p build && $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/FlashAttention.s $(KSRC)
+
+clean:
+	rm -f $(LIB) $(PKG)/fa_main tests/fa_test oracle/liboracle_attention.so
+	rm -rf build
+.PHONY: all oracle clean asm

@@ -1,0 +1,178 @@
+"""Host-side binding of the MI355X FlashAttention forward path.
+
+The product is ``libflash_attention.so`` (hand-written HIP for gfx950 behind the C ABI declared in
+``include/flash_attention.h``).  This module is the thin Python mirror of the reference's two
+entry points for that path:
+
+* ``flash_attention(Q, K, V, O, ...)`` -- the launch signature of
+  ``twoLoaderMhaFlashAttentionKernel`` (reference ``kernels/FlashAttention.cuh:59-63``; launched at
+  ``tests/main.cu:60-61``): dense ``[B, H, S, d]`` device tensors, ``scale``, ``is_causal``.
+* ``multi_head_attention(Q, K, V, num_heads)`` -- the reference's Python oracle API
+  (``check.py:4-25``): ``(B, S, d_model)`` tensors; the ``(B,S,H,d_k) -> (B,H,S,d_k)`` transposes of
+  ``check.py:14-16,24`` are done by strides inside the kernel, not by copies.
+
+PyTorch is used only for device memory and streams.  There is NO fallback: if the shared library
+is missing or the tensors are not on a GPU the call raises.  (The directory name contains '-', so
+the package is loaded through ``__graft_entry__.load_package()`` under the module name
+``flash_attention_cuda_c_amd``.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflash_attention.so")
+
+FA_DTYPE_F32, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3, FA_DTYPE_F16 = 0, 1, 2, 3
+
+# every symbol include/flash_attention.h declares
+EXPORTS = ("flash_attention", "flash_attention_strided", "flash_attention_plan",
+           "flash_attention_error_string", "flash_attention_version")
+
+
+class FaStrides(ctypes.Structure):
+    _fields_ = [("strideB", ctypes.c_int64), ("strideH", ctypes.c_int64), ("strideS", ctypes.c_int64)]
+
+
+class FaLaunchPlan(ctypes.Structure):
+    _fields_ = [("q_block_rows", ctypes.c_int), ("kv_block_rows", ctypes.c_int),
+                ("threads", ctypes.c_int), ("grid", ctypes.c_int), ("lds_bytes", ctypes.c_int),
+                ("kernel_id", ctypes.c_int)]
+
+
+class FlashAttentionError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"flash_attention failed with code {code}: {text}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libflash_attention.so (in-tree build).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} not built: run `make` (or __graft_entry__.build()); there is no fallback path")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i, f, b = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_bool
+        L.flash_attention.argtypes = [vp, vp, vp, vp, i, i, i, i, f, b, i, i, vp]
+        L.flash_attention.restype = i
+        sp = ctypes.POINTER(FaStrides)
+        L.flash_attention_strided.argtypes = [vp, vp, vp, vp, i, i, i, i, f, b, i, i, sp, sp, sp, sp, vp]
+        L.flash_attention_strided.restype = i
+        L.flash_attention_plan.argtypes = [i, i, i, i, b, i, i, ctypes.POINTER(FaLaunchPlan)]
+        L.flash_attention_plan.restype = i
+        L.flash_attention_error_string.argtypes = [i]
+        L.flash_attention_error_string.restype = ctypes.c_char_p
+        L.flash_attention_version.argtypes = []
+        L.flash_attention_version.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def version() -> str:
+    return lib().flash_attention_version().decode()
+
+
+def error_string(code: int) -> str:
+    return lib().flash_attention_error_string(int(code)).decode()
+
+
+def _check(code: int):
+    if code != 0:
+        raise FlashAttentionError(code, error_string(code))
+
+
+def _dtype_code(t):
+    import torch
+    table = {torch.float32: FA_DTYPE_F32, torch.bfloat16: FA_DTYPE_BF16, torch.float16: FA_DTYPE_F16}
+    if hasattr(torch, "float8_e4m3fn"):
+        table[torch.float8_e4m3fn] = FA_DTYPE_FP8_E4M3
+    if t not in table:
+        raise TypeError(f"unsupported dtype {t}")
+    return table[t]
+
+
+def _stream_ptr(stream):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def plan(batchSize, numHeads, seqLen, dHead, is_causal=False, dtype=FA_DTYPE_BF16, o_dtype=FA_DTYPE_F32):
+    """Launch geometry the library will use (counterpart of the reference's helpers.hpp:8-36)."""
+    p = FaLaunchPlan()
+    _check(lib().flash_attention_plan(batchSize, numHeads, seqLen, dHead, bool(is_causal), dtype, o_dtype,
+                                      ctypes.byref(p)))
+    return {k: getattr(p, k) for k, _ in FaLaunchPlan._fields_}
+
+
+def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None, stream=None):
+    """O = softmax(scale * Q K^T [+ causal mask]) V on dense [B, H, S, d] device tensors.
+
+    Argument order and meaning follow the reference kernel (Q, K, V, O, batchSize, numHeads,
+    seqLen, scale, is_causal -- kernels/FlashAttention.cuh:59-63); batchSize/numHeads/seqLen/dHead
+    are read from Q.shape, ``scale`` defaults to 1/sqrt(d) (tests/main.cu:27).  Asynchronous on
+    ``stream`` (default: torch's current stream).  Returns O.
+    """
+    import torch
+    if not (Q.is_cuda and K.is_cuda and V.is_cuda):
+        raise RuntimeError("flash_attention needs device tensors (no CPU fallback)")
+    if Q.dim() != 4 or Q.shape != K.shape or Q.shape != V.shape:
+        raise ValueError("Q, K, V must be [B, H, S, d] tensors of one shape")
+    if not (Q.dtype == K.dtype == V.dtype):
+        raise TypeError("Q, K, V must share a dtype")
+    B, H, S, d = Q.shape
+    if scale is None:
+        scale = 1.0 / float(d) ** 0.5
+    if O is None:
+        O = torch.empty((B, H, S, d), dtype=out_dtype or (torch.float32 if Q.dtype == torch.float32 else Q.dtype),
+                        device=Q.device)
+    elif O.shape != Q.shape or not O.is_cuda:
+        raise ValueError("O must be a device tensor shaped like Q")
+    dense = all(t.is_contiguous() for t in (Q, K, V, O))
+    with torch.cuda.device(Q.device):
+        if dense:
+            rc = lib().flash_attention(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, S, d,
+                                       float(scale), bool(is_causal), _dtype_code(Q.dtype), _dtype_code(O.dtype),
+                                       _stream_ptr(stream))
+        else:
+            st = []
+            for t in (Q, K, V, O):
+                if t.stride(3) != 1:
+                    raise ValueError("last dimension must be contiguous")
+                st.append(FaStrides(t.stride(0), t.stride(1), t.stride(2)))
+            rc = lib().flash_attention_strided(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, S, d,
+                                               float(scale), bool(is_causal), _dtype_code(Q.dtype),
+                                               _dtype_code(O.dtype), ctypes.byref(st[0]), ctypes.byref(st[1]),
+                                               ctypes.byref(st[2]), ctypes.byref(st[3]), _stream_ptr(stream))
+    _check(rc)
+    return O
+
+
+def multi_head_attention(Q, K, V, num_heads, is_causal=False, return_attn=False, out_dtype=None):
+    """Drop-in for the reference's ``check.py:multi_head_attention(Q, K, V, num_heads)``.
+
+    Q, K, V: (batch, seq_len, d_model) device tensors.  Returns ``(output, attn)`` like check.py:25,
+    with output (batch, seq_len, d_model); the (B,H,S,S) attention matrix is never materialised by
+    the fused kernel, so ``attn`` is None (``return_attn=True`` raises -- SURVEY.md section 8f row 4).
+    The head split / merge of check.py:14-16,24 is done with strides: no transpose copies.
+    """
+    import torch
+    if return_attn:
+        raise NotImplementedError("the fused forward kernel does not materialise attn (B,H,S,S)")
+    if Q.dim() != 3:
+        raise ValueError("Q, K, V must be (batch, seq_len, d_model)")
+    B, S, dm = Q.shape
+    if dm % num_heads != 0:
+        raise ValueError("d_model must be divisible by num_heads")
+    dk = dm // num_heads                                                 # check.py:11
+    out = torch.empty((B, S, dm), device=Q.device,
+                      dtype=out_dtype or (torch.float32 if Q.dtype == torch.float32 else Q.dtype))
+    view = lambda t: t.view(B, S, num_heads, dk).transpose(1, 2)         # check.py:14-16 (views only)
+    flash_attention(view(Q), view(K), view(V), view(out), scale=1.0 / float(dk) ** 0.5, is_causal=is_causal)
+    return out, None

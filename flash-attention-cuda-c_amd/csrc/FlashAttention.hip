@@ -1,0 +1,277 @@
+// FlashAttention.hip -- kernel entries and the C-ABI launcher (include/flash_attention.h).
+//
+// Counterpart of the reference's kernels/FlashAttention.cuh:59-84 (kernel entry: role split into
+// compute warps + two loader warps around four cuda::pipeline objects) and of the launch code in
+// tests/main.cu:51-64.  Written for gfx950 only: hipcc --offload-arch=gfx950.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/flash_attention.h"
+#include "../helpers.hpp"
+#include "computers.hip.h"
+#include "generic.hip.h"
+
+namespace fa {
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA forward kernel.  One workgroup = 8 waves = 256 query rows of one (batch, head);
+// each wave owns 32 rows; KV tiles of 64 keys are double-buffered in LDS.
+//
+// Per tile:   issue global loads of tile t+1 (registers)      <- HBM/L2 latency hides below
+//             S^T = K.Q^T      16 (D=128) MFMA 32x32x16, K fragments by ds_read_b128
+//             online softmax   in registers
+//             O^T += V^T.P^T   16 MFMA, V^T fragments by ds_read_b64_tr_b16
+//             write tile t+1 into the other LDS buffer; one barrier
+// ------------------------------------------------------------------------------------------------
+template <int D, bool CAUSAL, typename OutT>
+__global__ __launch_bounds__(512, 2) void fwd_bf16_kernel(const Params p) {
+    using Stage = KVStage<D>;
+    constexpr int KVBLK = 64, QBLK = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    lds_ptr smem = (lds_ptr)smem_raw;
+    // [buf0: K image | V image][buf1: K image | V image]
+    constexpr int BUF_BYTES = 2 * Stage::TILE_BYTES;
+
+    int g, qb;
+    if (!unit_of_block(p, CAUSAL, g, qb)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = g / p.H, h = g - b * p.H;
+    const int S = p.S;
+
+    const char* Qh = (const char*)p.Q + (b * p.qB + h * p.qH) * 2;
+    const char* Kh = (const char*)p.K + (b * p.kB + h * p.kH) * 2;
+    const char* Vh = (const char*)p.V + (b * p.vB + h * p.vH) * 2;
+    char* Oh = (char*)p.O + (b * p.oB + h * p.oH) * (int64_t)sizeof(OutT);
+    const int64_t qSb = p.qS * 2, kSb = p.kS * 2, vSb = p.vS * 2, oSb = p.oS * (int64_t)sizeof(OutT);
+
+    const int q_row0 = qb * QBLK + wave * 32;       // first query row of this wave
+    const int q_end = min(S, (qb + 1) * QBLK);      // one past the last query row of the block
+    const int n_tiles = CAUSAL ? (q_end + KVBLK - 1) / KVBLK : (S + KVBLK - 1) / KVBLK;
+    // tiles this wave computes: all (non-causal) or up to its own diagonal (causal)
+    const bool wave_live = q_row0 < S;
+    const int my_tiles = !wave_live ? 0 : (CAUSAL ? min(n_tiles, (q_row0 + 31) / KVBLK + 1) : n_tiles);
+
+    WaveCompute<D> wc;
+    wc.init();
+    wc.load_q(Qh, qSb, q_row0, S, lane);
+
+    Stage st;
+    st.load(Kh, Vh, kSb, vSb, 0, S, wave, lane);
+    st.write(smem, smem + Stage::TILE_BYTES, wave, lane);
+    __syncthreads();
+
+    const int kbase = k_read_base(lane);
+    const int vbase = v_read_base(lane);
+    const float c = p.scale_log2;
+
+    for (int t = 0; t < n_tiles; ++t) {
+        lds_ptr kimg = smem + (t & 1) * BUF_BYTES;
+        lds_ptr vimg = kimg + Stage::TILE_BYTES;
+        const bool more = t + 1 < n_tiles;
+        if (more) st.load(Kh, Vh, kSb, vSb, (t + 1) * KVBLK, S, wave, lane);
+
+        if (t < my_tiles) {
+            const int kv0 = t * KVBLK;
+            f32x16 s0 = wc.qk_tile(kimg, kbase, 0);
+            f32x16 s1 = wc.qk_tile(kimg, kbase, 1);
+            const bool need_mask = (CAUSAL && kv0 + KVBLK - 1 > q_row0) || (kv0 + KVBLK > S);
+            if (need_mask) {
+                wc.template mask_tile<CAUSAL>(s0, 0, kv0, q_row0, S, lane);
+                wc.template mask_tile<CAUSAL>(s1, 1, kv0, q_row0, S, lane);
+            }
+            bf16x8 pf[4];
+            wc.softmax_tile(s0, s1, c, pf);
+            wc.pv_tile(vimg, vbase, pf);
+        }
+
+        if (more) {
+            lds_ptr knext = smem + ((t + 1) & 1) * BUF_BYTES;
+            st.write(knext, knext + Stage::TILE_BYTES, wave, lane);
+        }
+        __syncthreads();
+    }
+
+    if (wave_live) wc.template store_o<OutT>(Oh, oSb, q_row0, S, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int fill_params(Params& p, const void* Q, const void* K, const void* V, void* O, int B, int H,
+                       int S, int d, float scale, const fa_strides* sQ, const fa_strides* sK,
+                       const fa_strides* sV, const fa_strides* sO) {
+    p.Q = Q; p.K = K; p.V = V; p.O = O;
+    const int64_t dS = d, dH = (int64_t)S * d, dB = (int64_t)H * S * d;
+    p.qB = sQ ? sQ->strideB : dB; p.qH = sQ ? sQ->strideH : dH; p.qS = sQ ? sQ->strideS : dS;
+    p.kB = sK ? sK->strideB : dB; p.kH = sK ? sK->strideH : dH; p.kS = sK ? sK->strideS : dS;
+    p.vB = sV ? sV->strideB : dB; p.vH = sV ? sV->strideH : dH; p.vS = sV ? sV->strideS : dS;
+    p.oB = sO ? sO->strideB : dB; p.oH = sO ? sO->strideH : dH; p.oS = sO ? sO->strideS : dS;
+    p.B = B; p.H = H; p.S = S;
+    p.scale = scale;
+    p.scale_log2 = scale * 1.4426950408889634f;
+    return FA_OK;
+}
+
+static int elem_size(int dtype) {
+    switch (dtype) {
+        case FA_DTYPE_F32: return 4;
+        case FA_DTYPE_BF16: case FA_DTYPE_F16: return 2;
+        case FA_DTYPE_FP8_E4M3: return 1;
+        default: return 0;
+    }
+}
+
+static bool strides_ok(const fa_strides* s, int esz, int d) {
+    if (!s) return true;
+    if (s->strideS < d || s->strideB < 0 || s->strideH < 0) return false;
+    return (s->strideS * esz) % 16 == 0 && (s->strideH * esz) % 16 == 0 && (s->strideB * esz) % 16 == 0;
+}
+
+static int validate(const void* Q, const void* K, const void* V, void* O, int B, int H, int S, int d,
+                    float scale, int dtype, int o_dtype) {
+    if (!Q || !K || !V || !O) return FA_ERR_NULL_POINTER;
+    if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return FA_ERR_MISALIGNED;
+    if (B <= 0 || H <= 0 || S <= 0 || d <= 0) return FA_ERR_BAD_SHAPE;
+    if ((int64_t)B * H > INT32_MAX / 2 || S > (1 << 24)) return FA_ERR_BAD_SHAPE;
+    if (!std::isfinite(scale)) return FA_ERR_BAD_SCALE;
+    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16) return FA_ERR_UNSUPPORTED_DTYPE;
+    if (o_dtype != FA_DTYPE_F32 && o_dtype != FA_DTYPE_BF16 && o_dtype != FA_DTYPE_F16) return FA_ERR_UNSUPPORTED_DTYPE;
+    if (d > 256) return FA_ERR_UNSUPPORTED_DHEAD;
+    if ((d * elem_size(dtype)) % 16 != 0 || (d * elem_size(o_dtype)) % 16 != 0) return FA_ERR_UNSUPPORTED_DHEAD;
+    return FA_OK;
+}
+
+static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_dtype, float scale,
+                     fa_launch_plan* plan) {
+    (void)causal; (void)o_dtype;
+    const bool mfma = dtype == FA_DTYPE_BF16 && (d == 64 || d == 128) && scale > 0.f;
+    if (mfma) {
+        plan->kernel_id = 1;
+        plan->q_block_rows = calculateSizeBlockQ(d, dtype);
+        plan->kv_block_rows = calculateSizeBlockKV(d, dtype);
+        plan->threads = 512;
+        plan->lds_bytes = 2 * 2 * plan->kv_block_rows * d * 2;
+        const int nQ = getNumCta(S, plan->q_block_rows);
+        const int64_t units = (int64_t)B * H * nQ;
+        plan->grid = (int)(8 * ((units + 7) / 8));
+    } else {
+        plan->kernel_id = 0;
+        plan->q_block_rows = GenericCfg::BQ;
+        plan->kv_block_rows = GenericCfg::BK;
+        plan->threads = GenericCfg::THREADS;
+        plan->lds_bytes = generic_lds_bytes(d);
+        const int nQ = getNumCta(S, plan->q_block_rows);
+        const int64_t units = (int64_t)B * H * nQ;
+        plan->grid = (int)(8 * ((units + 7) / 8));
+    }
+    return FA_OK;
+}
+
+template <int D, bool CAUSAL>
+static hipError_t launch_bf16(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
+    dim3 grid(plan.grid), block(plan.threads);
+    if (o_dtype == FA_DTYPE_F32)
+        hipLaunchKernelGGL((fwd_bf16_kernel<D, CAUSAL, float>), grid, block, plan.lds_bytes, st, p);
+    else if (o_dtype == FA_DTYPE_BF16)
+        hipLaunchKernelGGL((fwd_bf16_kernel<D, CAUSAL, __bf16>), grid, block, plan.lds_bytes, st, p);
+    else
+        hipLaunchKernelGGL((fwd_bf16_kernel<D, CAUSAL, _Float16>), grid, block, plan.lds_bytes, st, p);
+    return hipGetLastError();
+}
+
+template <typename InT, typename OutT>
+static hipError_t launch_generic_io(const Params& p, const fa_launch_plan& plan, int d, bool causal, hipStream_t st) {
+    dim3 grid(plan.grid), block(plan.threads);
+    if (causal)
+        hipLaunchKernelGGL((fwd_generic_kernel<InT, OutT, true>), grid, block, plan.lds_bytes, st, p, d);
+    else
+        hipLaunchKernelGGL((fwd_generic_kernel<InT, OutT, false>), grid, block, plan.lds_bytes, st, p, d);
+    return hipGetLastError();
+}
+
+template <typename InT>
+static hipError_t launch_generic(const Params& p, const fa_launch_plan& plan, int d, bool causal, int o_dtype, hipStream_t st) {
+    if (o_dtype == FA_DTYPE_F32) return launch_generic_io<InT, float>(p, plan, d, causal, st);
+    if (o_dtype == FA_DTYPE_BF16) return launch_generic_io<InT, __bf16>(p, plan, d, causal, st);
+    return launch_generic_io<InT, _Float16>(p, plan, d, causal, st);
+}
+
+static int run(const void* Q, const void* K, const void* V, void* O, int B, int H, int S, int d,
+               float scale, bool causal, int dtype, int o_dtype, const fa_strides* sQ,
+               const fa_strides* sK, const fa_strides* sV, const fa_strides* sO, void* stream) {
+    int rc = validate(Q, K, V, O, B, H, S, d, scale, dtype, o_dtype);
+    if (rc != FA_OK) return rc;
+    const int esz = elem_size(dtype), osz = elem_size(o_dtype);
+    if (!strides_ok(sQ, esz, d) || !strides_ok(sK, esz, d) || !strides_ok(sV, esz, d) || !strides_ok(sO, osz, d))
+        return FA_ERR_BAD_STRIDE;
+    fa_launch_plan plan;
+    make_plan(B, H, S, d, causal, dtype, o_dtype, scale, &plan);
+    Params p;
+    fill_params(p, Q, K, V, O, B, H, S, d, scale, sQ, sK, sV, sO);
+    p.nQ = getNumCta(S, plan.q_block_rows);
+    p.units = B * H * p.nQ;
+    p.cpx = (p.units + 7) / 8;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (plan.kernel_id == 1) {
+        if (d == 128) e = causal ? launch_bf16<128, true>(p, plan, o_dtype, st) : launch_bf16<128, false>(p, plan, o_dtype, st);
+        else          e = causal ? launch_bf16<64, true>(p, plan, o_dtype, st) : launch_bf16<64, false>(p, plan, o_dtype, st);
+    } else if (dtype == FA_DTYPE_F32) {
+        e = launch_generic<float>(p, plan, d, causal, o_dtype, st);
+    } else {
+        e = launch_generic<__bf16>(p, plan, d, causal, o_dtype, st);
+    }
+    return (int)e;
+}
+
+}  // namespace fa
+
+extern "C" {
+
+int flash_attention(const void* Q, const void* K, const void* V, void* O, int batchSize, int numHeads,
+                    int seqLen, int dHead, float scale, bool is_causal, int dtype, int o_dtype,
+                    void* stream) {
+    return fa::run(Q, K, V, O, batchSize, numHeads, seqLen, dHead, scale, is_causal, dtype, o_dtype,
+                   nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int flash_attention_strided(const void* Q, const void* K, const void* V, void* O, int batchSize,
+                            int numHeads, int seqLen, int dHead, float scale, bool is_causal, int dtype,
+                            int o_dtype, const fa_strides* sQ, const fa_strides* sK,
+                            const fa_strides* sV, const fa_strides* sO, void* stream) {
+    return fa::run(Q, K, V, O, batchSize, numHeads, seqLen, dHead, scale, is_causal, dtype, o_dtype, sQ,
+                   sK, sV, sO, stream);
+}
+
+int flash_attention_plan(int batchSize, int numHeads, int seqLen, int dHead, bool is_causal, int dtype,
+                         int o_dtype, fa_launch_plan* plan) {
+    if (!plan) return FA_ERR_NULL_POINTER;
+    if (batchSize <= 0 || numHeads <= 0 || seqLen <= 0 || dHead <= 0) return FA_ERR_BAD_SHAPE;
+    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16) return FA_ERR_UNSUPPORTED_DTYPE;
+    if (dHead > 256 || (dHead * fa::elem_size(dtype)) % 16 != 0) return FA_ERR_UNSUPPORTED_DHEAD;
+    return fa::make_plan(batchSize, numHeads, seqLen, dHead, is_causal, dtype, o_dtype, 1.0f, plan);
+}
+
+const char* flash_attention_error_string(int code) {
+    switch (code) {
+        case FA_OK: return "success";
+        case FA_ERR_NULL_POINTER: return "null pointer argument";
+        case FA_ERR_MISALIGNED: return "base pointer not 16-byte aligned";
+        case FA_ERR_BAD_SHAPE: return "batchSize/numHeads/seqLen/dHead out of range";
+        case FA_ERR_UNSUPPORTED_DHEAD: return "unsupported dHead for this dtype";
+        case FA_ERR_UNSUPPORTED_DTYPE: return "unsupported dtype / o_dtype";
+        case FA_ERR_BAD_SCALE: return "scale is not finite";
+        case FA_ERR_BAD_STRIDE: return "bad or misaligned stride";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown flash_attention error";
+    }
+}
+
+const char* flash_attention_version(void) { return "fa-mi355x 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// utils.hip.h -- fragment types, wave-64 cross-lane helpers and numeric conversions for gfx950.
+//
+// Counterpart of the reference's kernels/utils.cuh:10-15,49-55,84-90 (pipe_t / WARP / lane masks /
+// cooperative-groups reductions).  Nothing of that file transfers: a CDNA4 wavefront is 64 lanes,
+// there is no cuda::pipeline and no partial-warp shuffle mask.  Reductions here are in-register:
+// with the swapped QK^T orientation (computers.hip.h) a score row lives in ONE lane pair
+// (l, l+32), so the row max / row sum need a single v_permlane32_swap instead of the
+// reference's cg::reduce + Bc-1 __shfl_down_sync chain (kernels/utils.cuh:66-73).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fa {
+
+constexpr int WAVE = 64;  // hard-coded: gfx950 wavefront (reference: #define WARP 32, utils.cuh:12)
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define FA_LDS __attribute__((address_space(3)))
+typedef FA_LDS char* lds_ptr;
+
+// ---- MFMA wrappers: D = A*B + C on one wave, 32x32 output tile, K = 16 ------------------------
+// Operand lane maps (guide cdna_hip_programming.md section 3): lane l, r = l&31, h = l>>5 holds
+// A[row r][k = 8h+j], B[k = 8h+j][col r], j = 0..7; C/D: col = l&31, row = (reg&3)+8*(reg>>2)+4h.
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_32x32x16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// Row of the 32x32 accumulator tile held in register `reg` of lane half `h`.
+__host__ __device__ constexpr int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ---- LDS accessors ------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 lds_read_b128(lds_ptr base, int byte_off) {
+    return *reinterpret_cast<FA_LDS const bf16x8*>(base + byte_off);
+}
+__device__ __forceinline__ void lds_write_b128(lds_ptr base, int byte_off, u32x4 v) {
+    *reinterpret_cast<FA_LDS u32x4*>(base + byte_off) = v;
+}
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements is returned
+// column-major: lane i of the group gets column i, rows 0..3 in elements 0..3.  Lane 4q+p supplies
+// the address of row q, columns 4p..4p+3 (8-byte aligned).  EXEC must be all ones.
+__device__ __forceinline__ s16x4 lds_read_tr16_b64(lds_ptr base, int byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<FA_LDS s16x4*>(base + byte_off));
+}
+
+// ---- cross-half exchange: value of lane l^32 ---------------------------------------------------
+__device__ __forceinline__ float other_half(float x) {
+    // v_permlane32_swap vdst, src swaps vdst[32..63] with src[0..31]; with both = x the pair
+    // (r[0], r[1]) holds {own, partner} in some order on every lane.
+    const uint32_t u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const bool lo = (threadIdx.x & 32) == 0;
+    return __uint_as_float(lo ? r[1] : r[0]);
+}
+__device__ __forceinline__ float max_both_halves(float x) {
+    const uint32_t u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_both_halves(float x) {
+    const uint32_t u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// ---- conversions ---------------------------------------------------------------------------------
+// bf16 -> f32 is exact: place the 16 bits in the high half.
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+
+// Plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) for adjacent pairs.
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    f16x2 v;
+    v[0] = (_Float16)lo;
+    v[1] = (_Float16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+template <typename T> struct elem_traits;
+template <> struct elem_traits<float> {
+    __device__ static float load(const float* p) { return *p; }
+    __device__ static void store(float* p, float v) { *p = v; }
+};
+template <> struct elem_traits<__bf16> {
+    __device__ static float load(const __bf16* p) { return (float)*p; }
+    __device__ static void store(__bf16* p, float v) { *p = (__bf16)v; }
+};
+template <> struct elem_traits<_Float16> {
+    __device__ static float load(const _Float16* p) { return (float)*p; }
+    __device__ static void store(_Float16* p, float v) { *p = (_Float16)v; }
+};
+
+}  // namespace fa

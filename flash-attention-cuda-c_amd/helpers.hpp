@@ -1,0 +1,32 @@
+// helpers.hpp -- launch-geometry policy for gfx950.
+//
+// Counterpart of the reference's helpers.hpp:8-36.  There, calculateSizeBlockQ / calculateSizeBlockKV
+// sketch formulas in comments (Br <= regs/(d*4), helpers.hpp:9-14; Bc <= L2/(2*d*4), :22-25) and then
+// both `return 64` (:18,:29) -- sizes the reference kernel cannot even launch with.
+// Here the sizes are what the MI355X kernels are built around:
+//
+//   Br (query rows / workgroup): 8 waves x 32 rows = 256 for the MFMA kernels.  32 rows per wave
+//      is one 32x32 MFMA tile; 8 waves = 2 per SIMD share every K/V tile staged in LDS, which
+//      halves L2->LDS traffic per FLOP against a 4-wave workgroup.  Register budget per lane at
+//      2 waves/SIMD is 256: O^T accumulators 16*d/32, Q fragments 4*d/16, scores 32, P 16,
+//      staging 8*d/64 -- about 200 at d = 128.
+//   Bc (keys / tile): 64.  Two 32-key score tiles per wave; K + V tile = 32 KiB at d = 128,
+//      double-buffered = 64 KiB of the CU's 160 KiB LDS.
+//   generic exact-fp32 kernel: Br = Bc = 32 (VALU path, any d <= 256, any seqLen).
+#pragma once
+
+#include "../include/flash_attention.h"
+
+inline int calculateSizeBlockQ(int d_head, int dtype) {
+    if (dtype == FA_DTYPE_BF16 && (d_head == 64 || d_head == 128)) return 256;
+    return 32;
+}
+
+inline int calculateSizeBlockKV(int d_head, int dtype) {
+    if (dtype == FA_DTYPE_BF16 && (d_head == 64 || d_head == 128)) return 64;
+    return 32;
+}
+
+// Number of query blocks.  The reference asserts q_dim % q_block_size == 0 (helpers.hpp:34); the
+// MI355X kernels handle a ragged last block, so this is a ceiling division.
+inline int getNumCta(int q_dim, int q_block_size) { return (q_dim + q_block_size - 1) / q_block_size; }

@@ -1,0 +1,133 @@
+/*
+ * flash_attention.h -- C ABI of the MI355X-native FlashAttention forward path.
+ *
+ * Drop-in boundary for the ONE hot path of GMichailov/Flash-Attention-CUDA-C: the fused
+ * QK^T -> online softmax -> PV forward kernel
+ *
+ *     template<int D_HEAD,int Q_TILE_ROWS,int KV_TILE_ROWS> __global__
+ *     void twoLoaderMhaFlashAttentionKernel(const float* Q, const float* K, const float* V,
+ *                                           float* O, int batchSize, int numHeads, int seqLen,
+ *                                           float scale, bool is_causal)
+ *                                                   (reference kernels/FlashAttention.cuh:59-63)
+ *
+ * and its only host-side launcher test_flash_attention<...>() (reference tests/main.cu:21-103).
+ * The reference has no symbol literally named flash_attention; BASELINE.json's north_star gives
+ * that name to the launch signature above, so this library exports it with the kernel's
+ * parameters in the kernel's order (Q,K,V,O,batchSize,numHeads,seqLen,...,scale,is_causal).
+ * D_HEAD becomes a runtime argument; tile sizes are an internal policy (helpers.hpp), not ABI.
+ *
+ * Contract (same as the reference, tests/main.cu:39-48,60-64,99-102):
+ *   - Q,K,V,O are DEVICE pointers to dense row-major [batchSize, numHeads, seqLen, dHead]
+ *     tensors, element (b,h,s,j) at ((b*numHeads+h)*seqLen+s)*dHead+j
+ *     (reference kernels/loaders.cuh:57,92).  Base pointers 16-byte aligned.
+ *   - The caller owns all four buffers.  The library allocates nothing, frees nothing, keeps no
+ *     global state, never synchronises the host and never prints: the call enqueues work on
+ *     `stream` and returns (graph-capturable, re-entrant).  O is fully overwritten.
+ *   - is_causal masks key k > query q (reference kernels/utils.cuh:43, tests/main.cu:81).
+ *     Every query row keeps at least key 0, so no row is fully masked (the reference's NaN on
+ *     fully-masked tiles, SURVEY.md defect D3, is not reproduced).
+ *   - Each (b,h) pair is an independent problem (the reference mixes them: defect D2).
+ *
+ * Return value: 0 on success; > 0 a hipError_t from the launch; < 0 one of FA_ERR_* below.
+ * The library never calls exit() (the reference's CUDA_CHECK does, tests/main.cu:12-19).
+ *
+ * There is NO CPU fallback: on a machine without a gfx950 device the call fails with a HIP error.
+ */
+#ifndef FLASH_ATTENTION_H
+#define FLASH_ATTENTION_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Element types of Q/K/V (`dtype`) and of O (`o_dtype`). */
+enum {
+    FA_DTYPE_F32 = 0,      /* IEEE fp32 -- the reference's own type (const float*) */
+    FA_DTYPE_BF16 = 1,     /* bfloat16, fp32 accumulation on MFMA */
+    FA_DTYPE_FP8_E4M3 = 2, /* OCP e4m3fn (not fnuz); inputs only */
+    FA_DTYPE_F16 = 3       /* IEEE fp16; output only in this round */
+};
+
+/* Argument-validation errors (negative so they cannot collide with hipError_t). */
+enum {
+    FA_OK = 0,
+    FA_ERR_NULL_POINTER = -1,
+    FA_ERR_MISALIGNED = -2,       /* a base pointer is not 16-byte aligned */
+    FA_ERR_BAD_SHAPE = -3,        /* batchSize/numHeads/seqLen/dHead <= 0 or too large */
+    FA_ERR_UNSUPPORTED_DHEAD = -4,/* dHead not supported for this dtype */
+    FA_ERR_UNSUPPORTED_DTYPE = -5,
+    FA_ERR_BAD_SCALE = -6,        /* scale is NaN or infinite */
+    FA_ERR_BAD_STRIDE = -7
+};
+
+/*
+ * flash_attention -- replaces the <<<grid,block,smem>>> launch of
+ * twoLoaderMhaFlashAttentionKernel at reference tests/main.cu:60-61.
+ *
+ *   Q,K,V,O     device pointers, dense [batchSize,numHeads,seqLen,dHead]
+ *   dHead       reference template parameter D_HEAD (kernels/FlashAttention.cuh:59)
+ *   scale       multiplies QK^T before the softmax; the reference passes 1/sqrt(dHead)
+ *               (tests/main.cu:27, check.py:19)
+ *   dtype       element type of Q,K,V (FA_DTYPE_*)
+ *   o_dtype     element type of O; FA_DTYPE_F32 matches the reference's float* O
+ *   stream      hipStream_t (passed as void* so this header needs no HIP include); NULL = the
+ *               default stream
+ *
+ * Supported: f32 inputs, any dHead <= 256, any seqLen (exact-fp32 path);
+ *            bf16 inputs, dHead in {64,128} on the MFMA path (any seqLen >= 1), other dHead
+ *            <= 256 on the generic path; fp8 e4m3fn inputs, dHead in {64,128}.
+ */
+int flash_attention(const void* Q, const void* K, const void* V, void* O,
+                    int batchSize, int numHeads, int seqLen, int dHead,
+                    float scale, bool is_causal,
+                    int dtype, int o_dtype, void* stream);
+
+/*
+ * flash_attention_strided -- same path for tensors that are views of a (B,S,H*d_k) model-layout
+ * buffer (reference check.py:14-16,24) or any other layout whose last dimension is contiguous.
+ * Strides are in ELEMENTS: element (b,h,s,j) of X lives at b*strideB + h*strideH + s*strideS + j.
+ * This is the strided API the reference sketched and left commented out
+ * (kernels/FlashAttention.cuh:22-27: strideBatch / strideHead per tensor).
+ * Row starts must stay 16-byte aligned (strides multiples of 16 bytes).
+ */
+typedef struct fa_strides {
+    int64_t strideB, strideH, strideS;
+} fa_strides;
+
+int flash_attention_strided(const void* Q, const void* K, const void* V, void* O,
+                            int batchSize, int numHeads, int seqLen, int dHead,
+                            float scale, bool is_causal, int dtype, int o_dtype,
+                            const fa_strides* sQ, const fa_strides* sK, const fa_strides* sV,
+                            const fa_strides* sO, void* stream);
+
+/*
+ * Launch-geometry policy -- the counterpart of the reference's helpers.hpp:8-36
+ * (calculateSizeBlockQ / calculateSizeBlockKV / getNumCta, which return constants there).
+ * Fills the tile sizes and grid the library will use for this problem; returns 0 or FA_ERR_*.
+ */
+typedef struct fa_launch_plan {
+    int q_block_rows;    /* Br: query rows per workgroup          (helpers.hpp:8-19)  */
+    int kv_block_rows;   /* Bc: keys per inner-loop tile           (helpers.hpp:21-30) */
+    int threads;         /* threads per workgroup                  (tests/main.cu:52)  */
+    int grid;            /* number of workgroups                   (helpers.hpp:33-36) */
+    int lds_bytes;       /* dynamic LDS per workgroup              (tests/main.cu:55)  */
+    int kernel_id;       /* which internal kernel: 0 generic-f32 VALU, 1 bf16 MFMA, 2 fp8 MFMA */
+} fa_launch_plan;
+
+int flash_attention_plan(int batchSize, int numHeads, int seqLen, int dHead, bool is_causal,
+                         int dtype, int o_dtype, fa_launch_plan* plan);
+
+/* Human-readable text for a return code of the functions above (static storage). */
+const char* flash_attention_error_string(int code);
+
+/* Library version, e.g. "fa-mi355x 0.1 (gfx950)". */
+const char* flash_attention_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLASH_ATTENTION_H */

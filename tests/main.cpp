@@ -1,0 +1,221 @@
+// tests/main.cpp -- host launcher + CPU check, the counterpart of the reference's tests/main.cu:21-109
+// (allocate, copy in, launch, synchronise, copy out, compare with a naive CPU attention, print the
+// max absolute difference).  Differences: it calls the C ABI (include/flash_attention.h) instead of
+// a <<<>>> launch, uses random N(0,1) data as well as the reference's all-ones case (which cannot
+// see most bugs), checks against the oracle under oracle/ with a stated
+// tolerance, times the kernel with hipEvents, and exits non-zero on failure.
+//
+// usage: fa_test [--quick] [--perf] [--case B H S d causal dtype o_dtype]...
+//   dtype/o_dtype: 0 = f32, 1 = bf16, 3 = f16 (output only)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/flash_attention.h"
+#include "../oracle/cpu_attention.h"
+
+#define HIP_CHECK(x)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (x);                                                                  \
+        if (e_ != hipSuccess) {                                                               \
+            fprintf(stderr, "HIP error: %s (%s:%d)\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(2);                                                                          \
+        }                                                                                     \
+    } while (0)
+
+// counter-based N(0,1): splitmix64 of (seed, index) -> Box-Muller
+static inline uint64_t mix(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+static inline float gauss(uint64_t seed, uint64_t i) {
+    const uint64_t a = mix(seed * 0x100000001b3ull + 2 * i), b = mix(seed * 0x100000001b3ull + 2 * i + 1);
+    const double u1 = ((a >> 11) + 1.0) / 9007199254740993.0, u2 = (b >> 11) / 9007199254740992.0;
+    return (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2));
+}
+
+struct Case {
+    int B, H, S, d, causal, dtype, o_dtype;
+    int fill;  // 0 randn, 1 all ones (tests/main.cu:33-35), 2 spike (forces an online-softmax rescale)
+};
+
+static float f16_to_f32(uint16_t h) {
+    const uint32_t s = (h >> 15) & 1, e = (h >> 10) & 31, m = h & 1023;
+    float v;
+    if (e == 0) v = std::ldexp((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = std::ldexp(1.0f + m / 1024.0f, (int)e - 15);
+    return s ? -v : v;
+}
+
+struct Result {
+    double max_abs, max_rel, pass_frac, ms_med, ms_min, tflops;
+    bool ok;
+};
+
+static Result run_case(const Case& c, bool perf, int iters) {
+    const int64_t n = (int64_t)c.B * c.H * c.S * c.d;
+    const float scale = 1.0f / std::sqrt((float)c.d);  // tests/main.cu:27
+    std::vector<float> hq(n), hk(n), hv(n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (c.fill == 1) { hq[i] = hk[i] = hv[i] = 1.0f; }
+        else { hq[i] = gauss(1, i); hk[i] = gauss(2, i); hv[i] = gauss(3, i); }
+    }
+    if (c.fill == 2) {
+        // spike: in every head, key row S/2+5 is 6x query row 3 -> the max of row 3 jumps at that tile
+        for (int g = 0; g < c.B * c.H; ++g)
+            for (int j = 0; j < c.d; ++j)
+                hk[((int64_t)g * c.S + (c.S / 2 + 5) % c.S) * c.d + j] = 6.0f * hq[((int64_t)g * c.S + 3 % c.S) * c.d + j];
+    }
+    const int esz = c.dtype == FA_DTYPE_F32 ? 4 : 2;
+    const int osz = c.o_dtype == FA_DTYPE_F32 ? 4 : 2;
+    std::vector<uint16_t> bq, bk, bv;
+    if (c.dtype == FA_DTYPE_BF16) {
+        bq.resize(n); bk.resize(n); bv.resize(n);
+        for (int64_t i = 0; i < n; ++i) {
+            bq[i] = oracle_f32_to_bf16(hq[i]); hq[i] = oracle_bf16_to_f32(bq[i]);
+            bk[i] = oracle_f32_to_bf16(hk[i]); hk[i] = oracle_bf16_to_f32(bk[i]);
+            bv[i] = oracle_f32_to_bf16(hv[i]); hv[i] = oracle_bf16_to_f32(bv[i]);
+        }
+    }
+    void *dq, *dk, *dv, *dout;
+    HIP_CHECK(hipMalloc(&dq, n * esz)); HIP_CHECK(hipMalloc(&dk, n * esz));
+    HIP_CHECK(hipMalloc(&dv, n * esz)); HIP_CHECK(hipMalloc(&dout, n * osz));
+    const void *sq = esz == 4 ? (void*)hq.data() : (void*)bq.data();
+    const void *sk = esz == 4 ? (void*)hk.data() : (void*)bk.data();
+    const void *sv = esz == 4 ? (void*)hv.data() : (void*)bv.data();
+    HIP_CHECK(hipMemcpy(dq, sq, n * esz, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dk, sk, n * esz, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dv, sv, n * esz, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(dout, 0xff, n * osz));  // poison: every element must be overwritten
+
+    int rc = flash_attention(dq, dk, dv, dout, c.B, c.H, c.S, c.d, scale, c.causal != 0, c.dtype, c.o_dtype, nullptr);
+    if (rc != 0) { fprintf(stderr, "flash_attention failed: %d (%s)\n", rc, flash_attention_error_string(rc)); exit(3); }
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipGetLastError());
+
+    std::vector<float> out(n);
+    if (osz == 4) HIP_CHECK(hipMemcpy(out.data(), dout, n * 4, hipMemcpyDeviceToHost));
+    else {
+        std::vector<uint16_t> tmp(n);
+        HIP_CHECK(hipMemcpy(tmp.data(), dout, n * 2, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i)
+            out[i] = c.o_dtype == FA_DTYPE_BF16 ? oracle_bf16_to_f32(tmp[i]) : f16_to_f32(tmp[i]);
+    }
+
+    // CPU check.  Full tensor when cheap, otherwise a sample of heads (all rows of first/last head).
+    const double flops_full = 4.0 * c.B * c.H * (double)c.S * c.S * c.d;
+    std::vector<float> ref(n, 0.f);
+    std::vector<std::pair<int, int>> head_ranges;
+    const int BH = c.B * c.H;
+    if (flops_full <= 8e10 || BH <= 2) head_ranges.push_back({0, BH});
+    else { head_ranges.push_back({0, 1}); head_ranges.push_back({BH / 2, BH / 2 + 1}); head_ranges.push_back({BH - 1, BH}); }
+    for (auto hr : head_ranges)
+        oracle_attention_f64acc_rows(hq.data(), hk.data(), hv.data(), ref.data(), BH, c.S, c.d, scale, c.causal,
+                                     hr.first, hr.second, 0, c.S, 0);
+    // tolerance: |O - ref| <= atol + rtol*|ref|.  f32 inputs: exact-fp32 path.  bf16 inputs: P is
+    // rounded to bf16 before PV (2^-9 relative per weight), see DESIGN.md "Tolerance".
+    double atol, rtol;
+    if (c.dtype == FA_DTYPE_F32) { atol = 2e-5; rtol = 1e-4; }
+    else { atol = 4e-3; rtol = 4e-3; }
+    if (c.o_dtype == FA_DTYPE_BF16) { atol += 4e-3; rtol += 4e-3; }
+    if (c.o_dtype == FA_DTYPE_F16) { atol += 5e-4; rtol += 1e-3; }
+    Result r{0, 0, 0, 0, 0, 0, true};
+    int64_t cnt = 0, pass = 0, nan = 0;
+    for (auto hr : head_ranges)
+        for (int64_t i = (int64_t)hr.first * c.S * c.d; i < (int64_t)hr.second * c.S * c.d; ++i) {
+            const double e = std::fabs((double)out[i] - ref[i]);
+            if (!(e == e)) { ++nan; ++cnt; continue; }
+            r.max_abs = std::max(r.max_abs, e);
+            if (std::fabs(ref[i]) > 1e-2) r.max_rel = std::max(r.max_rel, e / std::fabs(ref[i]));
+            pass += e <= atol + rtol * std::fabs(ref[i]);
+            ++cnt;
+        }
+    r.pass_frac = (double)pass / cnt;
+    r.ok = nan == 0 && pass == cnt;
+
+    if (perf) {
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i)
+            flash_attention(dq, dk, dv, dout, c.B, c.H, c.S, c.d, scale, c.causal != 0, c.dtype, c.o_dtype, nullptr);
+        std::vector<float> ms(iters);
+        for (int i = 0; i < iters; ++i) {
+            HIP_CHECK(hipEventRecord(e0, nullptr));
+            flash_attention(dq, dk, dv, dout, c.B, c.H, c.S, c.d, scale, c.causal != 0, c.dtype, c.o_dtype, nullptr);
+            HIP_CHECK(hipEventRecord(e1, nullptr));
+            HIP_CHECK(hipEventSynchronize(e1));
+            HIP_CHECK(hipEventElapsedTime(&ms[i], e0, e1));
+        }
+        std::sort(ms.begin(), ms.end());
+        r.ms_med = ms[iters / 2]; r.ms_min = ms[0];
+        const double flops = c.causal ? flops_full / 2 : flops_full;
+        r.tflops = flops / (r.ms_med * 1e-3) / 1e12;
+        HIP_CHECK(hipEventDestroy(e0)); HIP_CHECK(hipEventDestroy(e1));
+    }
+    HIP_CHECK(hipFree(dq)); HIP_CHECK(hipFree(dk)); HIP_CHECK(hipFree(dv)); HIP_CHECK(hipFree(dout));
+    printf("%s B=%d H=%d S=%d d=%d causal=%d in=%d out=%d fill=%d | max_abs=%.3e max_rel=%.3e pass=%.6f nan=%lld",
+           r.ok ? "PASS" : "FAIL", c.B, c.H, c.S, c.d, c.causal, c.dtype, c.o_dtype, c.fill, r.max_abs, r.max_rel,
+           r.pass_frac, (long long)nan);
+    if (perf) printf(" | med=%.4f ms min=%.4f ms %.1f TFLOP/s (%.1f%% of 2516.6)", r.ms_med, r.ms_min, r.tflops,
+                     100.0 * r.tflops / 2516.6);
+    printf("\n");
+    fflush(stdout);
+    return r;
+}
+
+int main(int argc, char** argv) {
+    bool perf = false, quick = false;
+    std::vector<Case> cases;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--perf") perf = true;
+        else if (a == "--quick") quick = true;
+        else if (a == "--case" && i + 7 < argc) {
+            Case c{atoi(argv[i + 1]), atoi(argv[i + 2]), atoi(argv[i + 3]), atoi(argv[i + 4]), atoi(argv[i + 5]),
+                   atoi(argv[i + 6]), atoi(argv[i + 7]), 0};
+            cases.push_back(c);
+            i += 7;
+        }
+    }
+    printf("%s\n", flash_attention_version());
+    if (cases.empty()) {
+        // the reference's own known-answer case: all ones, S=16, d=16, B=H=1, fp32 (tests/main.cu:24-36,107)
+        cases.push_back({1, 1, 16, 16, 0, 0, 0, 1});
+        cases.push_back({1, 1, 16, 16, 1, 0, 0, 1});
+        // fp32 generic path: ragged S, odd d, multi-head isolation
+        cases.push_back({1, 1, 128, 64, 0, 0, 0, 0});   // BASELINE cfg0 shape
+        cases.push_back({2, 3, 77, 40, 1, 0, 0, 0});
+        cases.push_back({1, 2, 300, 256, 0, 0, 0, 0});
+        // bf16 MFMA path
+        cases.push_back({1, 1, 64, 128, 0, 1, 0, 0});
+        cases.push_back({1, 1, 64, 128, 0, 1, 0, 1});
+        cases.push_back({1, 2, 256, 128, 0, 1, 0, 0});
+        cases.push_back({2, 2, 512, 128, 1, 1, 0, 0});
+        cases.push_back({1, 3, 1000, 128, 1, 1, 0, 0});   // ragged S
+        cases.push_back({1, 3, 333, 64, 0, 1, 0, 0});
+        cases.push_back({2, 2, 512, 64, 1, 1, 1, 0});     // bf16 out
+        cases.push_back({1, 2, 512, 128, 0, 1, 3, 0});    // f16 out
+        cases.push_back({1, 2, 1024, 128, 0, 1, 0, 2});   // spike: forces the rescale branch
+        cases.push_back({1, 2, 1024, 128, 1, 1, 0, 2});
+        cases.push_back({1, 2, 200, 80, 1, 1, 0, 0});     // bf16 on the generic path (d = 80)
+        if (!quick) {
+            cases.push_back({4, 8, 2048, 64, 0, 1, 0, 0});    // BASELINE cfg1
+            cases.push_back({8, 16, 4096, 128, 1, 1, 0, 0});  // BASELINE cfg2 (sampled heads)
+            cases.push_back({8, 16, 4096, 128, 0, 1, 0, 0});
+        }
+    }
+    int fails = 0;
+    for (const Case& c : cases) fails += !run_case(c, perf, 20).ok;
+    printf("%d case(s) failed\n", fails);
+    return fails ? 1 : 0;
+}
