@@ -1,0 +1,88 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, validates arguments before touching the GPU, and reports the launch plan (host logic).
+No compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as entry
+
+fa = entry.load_package()
+ROOT = entry.ROOT
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "flash_attention.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(flash_attention\w*)\s*\(", text))
+
+
+def test_library_exports_every_declared_symbol():
+    L = fa.lib()
+    declared = header_functions()
+    assert declared == set(fa.EXPORTS), declared ^ set(fa.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert "gfx950" in fa.version()
+
+
+def test_argument_validation_happens_before_any_launch():
+    L = fa.lib()
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    p = (p + 15) & ~15
+    ok_args = dict(B=1, H=1, S=16, d=16, scale=0.25, causal=False, dtype=0, o=0)
+
+    def call(Q=p, K=p, V=p, O=p, **kw):
+        a = dict(ok_args, **kw)
+        return L.flash_attention(Q, K, V, O, a["B"], a["H"], a["S"], a["d"], a["scale"], a["causal"], a["dtype"],
+                                 a["o"], None)
+
+    assert call(Q=None) == -1 and call(O=None) == -1                 # FA_ERR_NULL_POINTER
+    assert call(K=p + 4) == -2                                       # FA_ERR_MISALIGNED
+    assert call(S=0) == -3 and call(B=-1) == -3                      # FA_ERR_BAD_SHAPE
+    assert call(d=512) == -4 and call(d=3) == -4                     # FA_ERR_UNSUPPORTED_DHEAD
+    assert call(dtype=9) == -5 and call(o=2) == -5                   # FA_ERR_UNSUPPORTED_DTYPE
+    assert call(scale=float("nan")) == -6 and call(scale=float("inf")) == -6
+    for code in range(-7, 1):
+        assert fa.error_string(code)
+    assert "null" in fa.error_string(-1)
+
+
+def test_strided_validation():
+    L = fa.lib()
+    buf = (ctypes.c_char * 4096)()
+    p = (ctypes.addressof(buf) + 15) & ~15
+    bad = fa.FaStrides(64, 16, 8)       # strideS < d
+    good = fa.FaStrides(1024, 16, 64)
+    rc = L.flash_attention_strided(p, p, p, p, 1, 1, 16, 16, 0.25, False, 0, 0, ctypes.byref(bad),
+                                   ctypes.byref(good), ctypes.byref(good), ctypes.byref(good), None)
+    assert rc == -7
+    odd = fa.FaStrides(1024, 16, 18)    # 72-byte rows: not 16-byte aligned
+    rc = L.flash_attention_strided(p, p, p, p, 1, 1, 16, 16, 0.25, False, 0, 0, ctypes.byref(odd),
+                                   ctypes.byref(good), ctypes.byref(good), ctypes.byref(good), None)
+    assert rc == -7
+
+
+@pytest.mark.parametrize("B,H,S,d,causal,dtype,kid,br,bc", [
+    (8, 16, 4096, 128, True, fa.FA_DTYPE_BF16, 1, 256, 64),    # BASELINE cfg2
+    (4, 8, 2048, 64, False, fa.FA_DTYPE_BF16, 1, 256, 64),     # BASELINE cfg1
+    (1, 1, 16, 16, False, fa.FA_DTYPE_F32, 0, 32, 32),         # tests/main.cu:107
+    (1, 2, 200, 80, True, fa.FA_DTYPE_BF16, 0, 32, 32),        # bf16, d not in {64,128}
+])
+def test_launch_plan(B, H, S, d, causal, dtype, kid, br, bc):
+    p = fa.plan(B, H, S, d, causal, dtype, fa.FA_DTYPE_F32)
+    assert p["kernel_id"] == kid and p["q_block_rows"] == br and p["kv_block_rows"] == bc
+    n_q = -(-S // br)                                  # getNumCta: ceil, not the reference's assert
+    units = B * H * n_q
+    assert p["grid"] == 8 * (-(-units // 8)) and p["grid"] >= units
+    assert p["threads"] % 64 == 0 and p["lds_bytes"] <= 160 * 1024
+
+
+def test_no_cpu_fallback_in_binding():
+    torch = pytest.importorskip("torch")
+    x = torch.zeros(1, 1, 16, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fa.flash_attention(x, x, x)

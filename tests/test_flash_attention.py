@@ -1,0 +1,265 @@
+"""GPU parity tests: the HIP path behind the C ABI against the CPU oracle, the golden vectors
+minted from the reference's check.py, and size-independent properties at the BASELINE sizes.
+
+Tolerances (written here, justified in DESIGN.md "Tolerance"):
+  fp32 inputs  (exact-fp32 generic kernel):  |O - ref| <= 2e-5 + 1e-4 |ref|
+  bf16 inputs, fp32 O (MFMA kernel; P is rounded to bf16 before P.V -> 2^-9 relative per weight):
+               |O - ref| <= 4e-3 + 4e-3 |ref|   and   RMS error <= 1e-3
+  bf16 / f16 O add the output rounding (2^-9 / 2^-11 relative).
+BASELINE.json asks for rtol = 1e-3 against check.py; with bf16 operands that is not attainable
+element-wise: the RMS bound above is the 1e-3 statement that does hold.
+"""
+import numpy as np
+import pytest
+
+import __graft_entry__ as entry
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+fa = entry.load_package()
+import oracle  # noqa: E402  (checker only)
+
+DEV = "cuda:0"
+
+
+def tol_for(in_dtype, out_dtype):
+    if in_dtype == torch.float32:
+        atol, rtol = 2e-5, 1e-4
+    else:
+        atol, rtol = 4e-3, 4e-3
+    if out_dtype == torch.bfloat16:
+        atol, rtol = atol + 4e-3, rtol + 4e-3
+    if out_dtype == torch.float16:
+        atol, rtol = atol + 5e-4, rtol + 1e-3
+    return atol, rtol
+
+
+def randn(shape, seed, dtype):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float32).to(dtype)
+
+
+def run_gpu(Q, K, V, causal, out_dtype=torch.float32, scale=None):
+    O = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, out_dtype=out_dtype, scale=scale)
+    torch.cuda.synchronize()
+    return O.float().cpu().numpy()
+
+
+def check(O, ref, atol, rtol, rms=None):
+    assert np.isfinite(O).all()
+    err = np.abs(O - ref)
+    bad = err > atol + rtol * np.abs(ref)
+    assert not bad.any(), f"{bad.sum()} / {bad.size} outside tolerance, max abs err {err.max():.3e}"
+    if rms is not None:
+        assert np.sqrt(np.mean(err ** 2)) <= rms
+
+
+# ------------------------------------------------------------------ reference known-answer cases
+def test_known_answer_maincu_all_ones():
+    """tests/main.cu:24-36,107: B=H=1, S=16, d=16, fp32 all-ones, scale 1/sqrt(16) -> O == 1."""
+    one = torch.ones(1, 1, 16, 16)
+    for causal in (False, True):
+        np.testing.assert_allclose(run_gpu(one, one, one, causal), 1.0, atol=1e-6)
+
+
+def test_known_answer_checkpy_demo(golden):
+    """check.py:30-43 through the check.py-shaped API: ones (1,4,8), H=2 -> output == 1."""
+    one = torch.from_numpy(golden.load("F1", "Q")).to(DEV)
+    out, attn = fa.multi_head_attention(one, one, one, 2)
+    torch.cuda.synchronize()
+    assert attn is None
+    np.testing.assert_allclose(out.cpu().numpy(), golden.load("F1", "out"), atol=1e-6)
+
+
+# ------------------------------------------------------------------ golden vectors (from check.py)
+@pytest.mark.parametrize("name", ["F0", "F3", "F4", "F6"])
+def test_golden_fp32_through_checkpy_api(golden, name):
+    """(B,S,H*d_k) tensors in, strided kernel launch, against check.py's recorded output."""
+    meta = golden.meta(name)
+    Q, K, V = (torch.from_numpy(golden.load(name, k)).to(DEV) for k in "QKV")
+    out, _ = fa.multi_head_attention(Q, K, V, meta["num_heads"], is_causal=meta["causal"])
+    torch.cuda.synchronize()
+    atol, rtol = (2e-4, 2e-4) if name == "F6" else (2e-5, 1e-4)
+    check(out.cpu().numpy(), golden.load(name, "out"), atol, rtol)
+
+
+def test_golden_bf16_inputs(golden):
+    """F5: check.py on bf16-rounded inputs; the MFMA kernel gets the same values as bf16.
+    d=64, S=128 (BASELINE cfg0's shape) on the bf16 path."""
+    Q, K, V = (torch.from_numpy(golden.load("F5bf16", k)).to(torch.bfloat16) for k in "QKV")
+    for t, k in zip((Q, K, V), "QKV"):
+        np.testing.assert_array_equal(t.float().numpy(), golden.load("F5bf16", k))   # exact in bf16
+    out, _ = fa.multi_head_attention(Q.to(DEV), K.to(DEV), V.to(DEV), 1, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    check(out.cpu().numpy(), golden.load("F5bf16", "out"), 4e-3, 4e-3, rms=1e-3)
+
+
+def test_golden_layout_bf16_two_heads(golden):
+    """F3 pins (B,S,H*d_k) <-> [B,H,S,d] (check.py:14-16,24) on the MFMA path (d_k = 64)."""
+    Q, K, V = (torch.from_numpy(golden.load("F3", k)).to(torch.bfloat16) for k in "QKV")
+    ref, _ = oracle.multi_head_attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), 2)
+    out, _ = fa.multi_head_attention(Q.to(DEV), K.to(DEV), V.to(DEV), 2, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    check(out.cpu().numpy(), ref, 4e-3, 4e-3, rms=1e-3)
+
+
+# ------------------------------------------------------------------ random parity vs the oracle
+FP32_CASES = [(1, 1, 128, 64, False), (2, 3, 77, 40, True), (1, 2, 300, 256, False), (1, 1, 1, 16, True),
+              (1, 2, 33, 8, True), (3, 1, 65, 100, False)]
+
+
+@pytest.mark.parametrize("B,H,S,d,causal", FP32_CASES)
+def test_fp32_path_matches_oracle(B, H, S, d, causal):
+    Q, K, V = (randn((B, H, S, d), s, torch.float32) for s in (1, 2, 3))
+    ref = oracle.attention(Q.numpy(), K.numpy(), V.numpy(), causal=causal)
+    check(run_gpu(Q, K, V, causal), ref, *tol_for(torch.float32, torch.float32))
+
+
+BF16_CASES = [(1, 1, 64, 128, False), (1, 2, 256, 128, False), (2, 2, 512, 128, True), (1, 3, 1000, 128, True),
+              (1, 3, 333, 64, False), (1, 1, 1, 128, True), (1, 2, 63, 64, True), (1, 2, 65, 128, False),
+              (2, 1, 257, 128, True), (1, 1, 2048, 64, True), (1, 2, 200, 80, True), (1, 9, 320, 128, False)]
+
+
+@pytest.mark.parametrize("B,H,S,d,causal", BF16_CASES)
+def test_bf16_path_matches_oracle(B, H, S, d, causal):
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in (4, 5, 6))
+    ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=causal)
+    atol, rtol = tol_for(torch.bfloat16 if d in (64, 128) else torch.float32, torch.float32)
+    check(run_gpu(Q, K, V, causal), ref, atol, rtol, rms=1e-3)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
+def test_low_precision_outputs(out_dtype):
+    Q, K, V = (randn((2, 2, 512, 128), s, torch.bfloat16) for s in (7, 8, 9))
+    ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=True)
+    check(run_gpu(Q, K, V, True, out_dtype=out_dtype), ref, *tol_for(torch.bfloat16, out_dtype))
+
+
+def test_causal_edges():
+    """Row 0 sees one key (O[0] == V[0]); tile-boundary rows; a fully masked tile is skipped, never NaN
+    (reference defect D3)."""
+    Q, K, V = (randn((1, 2, 512, 128), s, torch.bfloat16) for s in (10, 11, 12))
+    O = run_gpu(Q, K, V, True)
+    np.testing.assert_allclose(O[:, :, 0], V.float().numpy()[:, :, 0], rtol=1e-6, atol=1e-6)
+    ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=True)
+    for r in (31, 32, 63, 64, 255, 256, 511):
+        check(O[:, :, r], ref[:, :, r], 4e-3, 4e-3)
+
+
+def test_online_softmax_rescale_is_forced():
+    """Spike one key against one query so the row max jumps by far more than the lazy-rescale
+    threshold in the middle of the sequence (guide rule: a rare data-dependent branch needs its own test)."""
+    B, H, S, d = 1, 2, 1024, 128
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in (13, 14, 15))
+    for row, key in ((3, S // 2 + 5), (700, 130), (1023, 1000)):
+        K[:, :, key] = (6.0 * Q[:, :, row].float()).to(torch.bfloat16)
+    for causal in (False, True):
+        ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=causal)
+        check(run_gpu(Q, K, V, causal), ref, 4e-3, 4e-3, rms=1e-3)
+
+
+def test_large_score_range_no_overflow():
+    """Scores of magnitude ~ +-300: exp must be taken relative to the running max."""
+    Q, K, V = (randn((1, 1, 256, 128), s, torch.bfloat16) for s in (16, 17, 18))
+    Q, K = Q * 6, K * 6
+    ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=False)
+    check(run_gpu(Q, K, V, False), ref, 8e-3, 8e-3)
+
+
+def test_heads_are_independent():
+    """Reference defect D2 (every query attends to every batch/head) must not be reproduced:
+    a head computed alone equals the same head computed inside a batch, bit for bit."""
+    Q, K, V = (randn((2, 3, 256, 128), s, torch.bfloat16) for s in (19, 20, 21))
+    full = run_gpu(Q, K, V, True)
+    for b in range(2):
+        for h in range(3):
+            one = run_gpu(Q[b:b + 1, h:h + 1], K[b:b + 1, h:h + 1], V[b:b + 1, h:h + 1], True)
+            np.testing.assert_array_equal(one[0, 0], full[b, h])
+
+
+def test_custom_scale_and_nonpositive_scale_route():
+    Q, K, V = (randn((1, 2, 192, 64), s, torch.bfloat16) for s in (22, 23, 24))
+    for scale in (0.5, 0.03, -0.2, 0.0):   # scale <= 0 takes the generic kernel
+        ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), scale=scale)
+        check(run_gpu(Q, K, V, False, scale=scale), ref, 4e-3, 4e-3)
+
+
+def test_every_output_element_is_written():
+    Q, K, V = (randn((1, 2, 300, 128), s, torch.bfloat16).to(DEV) for s in (25, 26, 27))
+    O = torch.full((1, 2, 300, 128), float("nan"), device=DEV)
+    fa.flash_attention(Q, K, V, O, is_causal=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(O).all()
+
+
+def test_runs_on_a_side_stream_and_is_deterministic():
+    Q, K, V = (randn((2, 4, 1024, 128), s, torch.bfloat16).to(DEV) for s in (28, 29, 30))
+    a = fa.flash_attention(Q, K, V, is_causal=True)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        b = fa.flash_attention(Q, K, V, is_causal=True)
+    st.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ BASELINE sizes
+def _sampled_check(B, H, S, d, causal, seeds, heads, rows):
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in seeds)
+    O = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    Of = O.cpu().numpy().reshape(B * H, S, d)
+    Qf, Kf, Vf = (t.float().numpy() for t in (Q, K, V))
+    for h0 in heads:
+        for (r0, r1) in rows:
+            ref = oracle.attention_rows(Qf, Kf, Vf, (h0, h0 + 1), (r0, r1), causal=causal)
+            check(Of[h0:h0 + 1, r0:r1], ref, 4e-3, 4e-3, rms=1e-3)
+    return Q, K, V, O
+
+
+def test_baseline_cfg1_full_tensor():
+    """BASELINE cfg1: bf16, B=4, H=8, S=2048, d=64, non-causal -- full-tensor compare (34 GFLOP on the CPU)."""
+    B, H, S, d = 4, 8, 2048, 64
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in (31, 32, 33))
+    ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=False)
+    check(run_gpu(Q, K, V, False), ref, 4e-3, 4e-3, rms=1e-3)
+
+
+def test_baseline_cfg2_sampled_and_properties():
+    """BASELINE cfg2 (headline): bf16, B=8, H=16, S=4096, d=128, causal.  Oracle on sampled heads/rows
+    (first, middle, last head; first rows, tile edges, last rows) + size-independent properties."""
+    B, H, S, d = 8, 16, 4096, 128
+    Q, K, V, O = _sampled_check(B, H, S, d, True, (34, 35, 36), heads=(0, 77, 127),
+                                rows=((0, 96), (2016, 2112), (4000, 4096)))
+    Qd, Kd, Vd = Q.to(DEV), K.to(DEV), V.to(DEV)
+    # (1) softmax rows sum to one: V == 1 gives O == 1 whatever Q, K are
+    ones = torch.ones_like(Vd)
+    O1 = fa.flash_attention(Qd, Kd, ones, is_causal=True, out_dtype=torch.float32)
+    assert float((O1 - 1).abs().max()) <= 4e-3
+    # (2) linearity in V: attn(V1 + V2) == attn(V1) + attn(V2) up to rounding (V2 = a second draw)
+    V2 = randn((B, H, S, d), 37, torch.bfloat16).to(DEV)
+    Vs = (Vd.float() + V2.float()).to(torch.bfloat16)
+    lhs = fa.flash_attention(Qd, Kd, Vs, is_causal=True, out_dtype=torch.float32)
+    rhs = O + fa.flash_attention(Qd, Kd, V2, is_causal=True, out_dtype=torch.float32)
+    assert float((lhs - rhs).abs().max()) <= 3e-2 and float((lhs - rhs).pow(2).mean().sqrt()) <= 2e-3
+    # (3) a head shard equals the unsharded result bit for bit (the multi-GPU partition, section 8e)
+    lo, hi = 48, 80
+    Os = fa.flash_attention(Qd.view(B * H, 1, S, d)[lo:hi], Kd.view(B * H, 1, S, d)[lo:hi],
+                            Vd.view(B * H, 1, S, d)[lo:hi], is_causal=True, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert torch.equal(Os.view(hi - lo, S, d), O.view(B * H, S, d)[lo:hi])
+    # (4) row 0 of every head under the causal mask is exactly V[0]
+    assert torch.equal(O[:, :, 0], Vd[:, :, 0].float())
+
+
+def test_noncausal_key_permutation_invariance():
+    """Non-causal attention does not depend on the order of the (key, value) pairs."""
+    B, H, S, d = 2, 4, 4096, 128
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16).to(DEV) for s in (38, 39, 40))
+    perm = torch.randperm(S, generator=torch.Generator().manual_seed(41)).to(DEV)
+    a = fa.flash_attention(Q, K, V, out_dtype=torch.float32)
+    b = fa.flash_attention(Q, K[:, :, perm].contiguous(), V[:, :, perm].contiguous(), out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert float((a - b).abs().max()) <= 4e-3
