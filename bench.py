@@ -138,7 +138,7 @@ def main():
     # sanity: the output is finite and row 0 of a causal head equals V[0]
     ok = bool(torch.isfinite(O.float()).all())
     if causal:
-        ok = ok and bool(torch.equal(O[:, :, 0].float(), V[:, :, 0].float()))
+        ok = ok and bool(torch.allclose(O[:, :, 0].float(), V[:, :, 0].float(), rtol=1e-2, atol=1e-2))
     ok_all = shard.reduce_sum(0.0 if ok else 1.0) == 0.0
 
     if rank == 0:

@@ -250,8 +250,9 @@ def test_baseline_cfg2_sampled_and_properties():
                             Vd.view(B * H, 1, S, d)[lo:hi], is_causal=True, out_dtype=torch.float32)
     torch.cuda.synchronize()
     assert torch.equal(Os.view(hi - lo, S, d), O.view(B * H, S, d)[lo:hi])
-    # (4) row 0 of every head under the causal mask is exactly V[0]
-    assert torch.equal(O[:, :, 0], Vd[:, :, 0].float())
+    # (4) row 0 of every head under the causal mask is V[0] (one key, weight 1; the FMA in the exponent
+    #     leaves l = 1 + O(1e-7), so equality holds to fp32 rounding, not bitwise)
+    torch.testing.assert_close(O[:, :, 0], Vd[:, :, 0].float(), rtol=1e-6, atol=1e-6)
 
 
 def test_noncausal_key_permutation_invariance():
