@@ -2,12 +2,12 @@
 PKG      := flash-attention-cuda-c_amd
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     := gfx950
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -fno-slp-vectorize
 LIB      := $(PKG)/libflash_attention.so
 KSRC     := $(PKG)/csrc/FlashAttention.hip
 KHDR     := $(wildcard $(PKG)/csrc/*.h) $(PKG)/helpers.hpp include/flash_attention.h
 
-all: $(LIB) oracle $(PKG)/fa_main tests/fa_test
+all: $(LIB) oracle $(PKG)/fa_main tests/fa_test tests/fa_tune
 
 $(LIB): $(KSRC) $(KHDR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KSRC)
@@ -26,6 +26,10 @@ oracle/liboracle_attention.so: oracle/cpu_attention.c oracle/cpu_attention.h
 tests/fa_test: tests/main.cpp $(LIB) oracle/liboracle_attention.so
 	$(HIPCC) -O2 -std=c++17 -o $@ tests/main.cpp -L$(PKG) -lflash_attention -Loracle -loracle_attention \
 	    -Wl,-rpath,'$$ORIGIN/../$(PKG)' -Wl,-rpath,'$$ORIGIN/../oracle'
+
+# kernel-variant A/B harness (tuning infrastructure)
+tests/fa_tune: tests/fa_tune.hip $(KHDR) oracle/liboracle_attention.so
+	$(HIPCC) $(HIPFLAGS) -o $@ tests/fa_tune.hip -Loracle -loracle_attention -Wl,-rpath,'$$ORIGIN/../oracle'
 
 asm: $(KSRC) $(KHDR)
 	mkdir -p build && $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/FlashAttention.s $(KSRC)

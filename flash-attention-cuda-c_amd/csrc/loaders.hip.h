@@ -34,6 +34,7 @@ struct Params {
     int cpx;          // ceil(units / 8): work units per XCD group
     float scale_log2; // scale * log2(e)
     float scale;
+    unsigned long long* dbg;  // diagnostic builds only (tests/fa_tune): per-wave segment cycle sums
 };
 
 // Workgroup -> (head, query block).  Blocks b and b+8 share an XCD (round-robin dispatch), so
@@ -70,8 +71,8 @@ struct KVStage {
     __device__ static int v_chunk(int i, int lane) { return 8 * i + 4 * (lane >> 5) + (lane & 3); }
 
     // LDS byte offsets inside one K / V tile image.
-    __device__ static int k_lds_off(int key, int chunk) { return chunk * (KVBLK * 16) + key * 16; }
-    __device__ static int v_lds_off(int key, int chunk) {
+    __host__ __device__ static constexpr int k_lds_off(int key, int chunk) { return chunk * (KVBLK * 16) + key * 16; }
+    __host__ __device__ static constexpr int v_lds_off(int key, int chunk) {
         return (key >> 3) * (DB * 512) + (chunk >> 2) * 512 + (key & 7) * 64 + (chunk & 3) * 16;
     }
 

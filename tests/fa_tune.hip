@@ -1,0 +1,239 @@
+// tests/fa_tune.hip -- A/B harness for kernel variants: instantiates several configurations of the
+// bf16 kernels side by side, checks each against the first (and a sampled oracle check), and times
+// them in INTERLEAVED rounds inside one process on random N(0,1) data (devices and separate runs
+// differ by more than the deltas being measured).  Test/tuning infrastructure, not product.
+//
+// usage: fa_tune [B H S d causal] [--rounds R] [--only i,j,...]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../flash-attention-cuda-c_amd/csrc/kernel_bf16.hip.h"
+#include "../flash-attention-cuda-c_amd/csrc/kernel_bf16_slots.hip.h"
+#include "../flash-attention-cuda-c_amd/csrc/kernel_bf16_v4.hip.h"
+#include "../flash-attention-cuda-c_amd/csrc/kernel_bf16_v1.hip.h"
+#include "../oracle/cpu_attention.h"
+
+#define HIP_CHECK(x)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (x);                                                                  \
+        if (e_ != hipSuccess) {                                                               \
+            fprintf(stderr, "HIP error: %s (%s:%d)\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(2);                                                                          \
+        }                                                                                     \
+    } while (0)
+
+using namespace fa;
+
+static inline uint64_t mix(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+static void fill_randn_bf16(std::vector<uint16_t>& v, uint64_t seed) {
+    for (size_t i = 0; i < v.size(); i += 2) {
+        const uint64_t a = mix(seed * 0x9e3779b1ull + i), b = mix(seed * 0x85ebca6bull + i + 1);
+        const double u1 = ((a >> 11) + 1.0) / 9007199254740993.0, u2 = (b >> 11) / 9007199254740992.0;
+        const double r = std::sqrt(-2.0 * std::log(u1));
+        v[i] = oracle_f32_to_bf16((float)(r * std::cos(6.283185307179586 * u2)));
+        if (i + 1 < v.size()) v[i + 1] = oracle_f32_to_bf16((float)(r * std::sin(6.283185307179586 * u2)));
+    }
+}
+
+struct Variant {
+    std::string name;
+    std::function<void(const Params&, int grid)> launch;
+};
+
+template <class K>
+static void launch_pipelined(const Params& p, int grid) {
+    constexpr int lds = 3 * 2 * KVStage<K::D>::TILE_BYTES;
+    static bool once = [] {
+        HIP_CHECK(hipFuncSetAttribute((const void*)fwd_bf16_pipelined_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((fwd_bf16_pipelined_kernel<K>), dim3(grid), dim3(512), lds, nullptr, p);
+}
+template <class K>
+static void launch_slots(const Params& p, int grid) {
+    constexpr int lds = 3 * 2 * KVStage<K::D>::TILE_BYTES;
+    static bool once = [] {
+        HIP_CHECK(hipFuncSetAttribute((const void*)fwd_bf16_slots_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((fwd_bf16_slots_kernel<K>), dim3(grid), dim3(512), lds, nullptr, p);
+}
+template <class K>
+static void launch_v4(const Params& p, int grid) {
+    constexpr int lds = 3 * 2 * KVStage<K::D>::TILE_BYTES;
+    static bool once = [] {
+        HIP_CHECK(hipFuncSetAttribute((const void*)fwd_bf16_v4_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((fwd_bf16_v4_kernel<K>), dim3(grid), dim3(512), lds, nullptr, p);
+}
+template <int D, bool CAUSAL>
+static void launch_v1(const Params& p, int grid) {
+    constexpr int lds = 2 * 2 * KVStage<D>::TILE_BYTES;
+    hipLaunchKernelGGL((fwd_bf16_kernel<D, CAUSAL, __bf16>), dim3(grid), dim3(512), lds, nullptr, p);
+}
+
+template <int D, bool CAUSAL>
+static std::vector<Variant> make_variants() {
+    std::vector<Variant> v;
+    v.push_back({"v1 2-slot unpipelined", launch_v1<D, CAUSAL>});
+    v.push_back({"v2 nosched", launch_pipelined<KernelCfg<D, CAUSAL, __bf16, 8, 8, 4, false>>});
+    v.push_back({"v3 slots npre4 vpre2", launch_slots<SlotCfg<D, CAUSAL, __bf16, 8, 4, 2>>});
+    v.push_back({"v4 npre4 vpre2", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 4, 2>>});
+    v.push_back({"v4 npre4 vpre2 prio1", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 4, 2, false, 1>>});
+    v.push_back({"v4 npre6 vpre3", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 6, 3>>});
+    v.push_back({"v4 npre4 vpre2 STAMP", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 4, 2, true>>});
+    return v;
+}
+
+int main(int argc, char** argv) {
+    int B = 8, H = 16, S = 4096, d = 128, causal = 0, rounds = 7;
+    std::vector<int> only;
+    std::vector<int> pos;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--rounds" && i + 1 < argc) rounds = atoi(argv[++i]);
+        else if (a == "--only" && i + 1 < argc) {
+            char* s = argv[++i];
+            for (char* t = strtok(s, ","); t; t = strtok(nullptr, ",")) only.push_back(atoi(t));
+        } else pos.push_back(atoi(argv[i]));
+    }
+    if (pos.size() >= 5) { B = pos[0]; H = pos[1]; S = pos[2]; d = pos[3]; causal = pos[4]; }
+    const int BH = B * H;
+    const size_t per_head = (size_t)S * d, n = per_head * BH;
+    const int distinct = std::min(BH, 8);
+    std::vector<uint16_t> hq(per_head * distinct), hk(per_head * distinct), hv(per_head * distinct);
+    fill_randn_bf16(hq, 1); fill_randn_bf16(hk, 2); fill_randn_bf16(hv, 3);
+    void *dq, *dk, *dv, *dref, *dout;
+    HIP_CHECK(hipMalloc(&dq, n * 2)); HIP_CHECK(hipMalloc(&dk, n * 2)); HIP_CHECK(hipMalloc(&dv, n * 2));
+    HIP_CHECK(hipMalloc(&dref, n * 2)); HIP_CHECK(hipMalloc(&dout, n * 2));
+    for (int t = 0; t < 3; ++t) {
+        char* dst = (char*)(t == 0 ? dq : t == 1 ? dk : dv);
+        const std::vector<uint16_t>& src = t == 0 ? hq : t == 1 ? hk : hv;
+        for (int g = 0; g < BH; g += distinct) {
+            const int cnt = std::min(distinct, BH - g);
+            HIP_CHECK(hipMemcpy(dst + (size_t)g * per_head * 2, src.data(), per_head * cnt * 2, hipMemcpyHostToDevice));
+        }
+    }
+    Params p{};
+    p.Q = dq; p.K = dk; p.V = dv; p.O = dout;
+    p.qS = p.kS = p.vS = p.oS = d;
+    p.qH = p.kH = p.vH = p.oH = (int64_t)S * d;
+    p.qB = p.kB = p.vB = p.oB = (int64_t)H * S * d;
+    p.B = B; p.H = H; p.S = S;
+    p.nQ = (S + 255) / 256;
+    p.units = BH * p.nQ;
+    p.cpx = (p.units + 7) / 8;
+    p.scale = 1.0f / std::sqrt((float)d);
+    p.scale_log2 = p.scale * 1.4426950408889634f;
+    const int grid = 8 * p.cpx;
+    unsigned long long* ddbg;
+    HIP_CHECK(hipMalloc(&ddbg, (size_t)grid * 64 * 8));
+    HIP_CHECK(hipMemset(ddbg, 0, (size_t)grid * 64 * 8));
+    p.dbg = ddbg;
+
+    std::vector<Variant> vars;
+    if (d == 128) vars = causal ? make_variants<128, true>() : make_variants<128, false>();
+    else if (d == 64) vars = causal ? make_variants<64, true>() : make_variants<64, false>();
+    else { fprintf(stderr, "d must be 64 or 128\n"); return 2; }
+    if (!only.empty()) {
+        std::vector<Variant> sel;
+        for (int i : only) if (i >= 0 && i < (int)vars.size()) sel.push_back(vars[i]);
+        vars = sel;
+    }
+
+    // correctness: oracle on head 0 (all rows) and the last head's last 64 rows; variants vs variant 0
+    std::vector<float> fq(per_head), fk(per_head), fv(per_head), ref(per_head);
+    auto host_head = [&](int g) {
+        const size_t off = (size_t)(g % distinct) * per_head;
+        for (size_t i = 0; i < per_head; ++i) {
+            fq[i] = oracle_bf16_to_f32(hq[off + i]); fk[i] = oracle_bf16_to_f32(hk[off + i]); fv[i] = oracle_bf16_to_f32(hv[off + i]);
+        }
+    };
+    std::vector<uint16_t> out0(n), outv(n);
+    printf("problem: B=%d H=%d S=%d d=%d causal=%d  grid=%d  rounds=%d\n", B, H, S, d, causal, grid, rounds);
+    for (size_t vi = 0; vi < vars.size(); ++vi) {
+        HIP_CHECK(hipMemset(dout, 0xff, n * 2));
+        vars[vi].launch(p, grid);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(outv.data(), dout, n * 2, hipMemcpyDeviceToHost));
+        double max_err = 0;
+        size_t bad = 0;
+        for (int g : {0, BH - 1}) {
+            host_head(g);
+            const int r0 = g == 0 ? 0 : S - 64;
+            oracle_attention_f64acc_rows(fq.data(), fk.data(), fv.data(), ref.data(), 1, S, d, p.scale, causal, 0, 1, r0, S, 0);
+            for (size_t i = (size_t)r0 * d; i < per_head; ++i) {
+                const double e = std::fabs((double)oracle_bf16_to_f32(outv[(size_t)g * per_head + i]) - ref[i]);
+                if (!(e <= 8e-3 + 8e-3 * std::fabs(ref[i]))) ++bad;
+                if (e == e) max_err = std::max(max_err, e);
+            }
+        }
+        double max_diff0 = 0;
+        if (vi == 0) out0 = outv;
+        else
+            for (size_t i = 0; i < n; ++i)
+                max_diff0 = std::max(max_diff0, (double)std::fabs(oracle_bf16_to_f32(outv[i]) - oracle_bf16_to_f32(out0[i])));
+        printf("  [%zu] %-32s oracle max_abs_err=%.3e bad=%zu  max|diff vs [0]|=%.3e %s\n", vi, vars[vi].name.c_str(), max_err,
+               bad, max_diff0, bad ? "FAIL" : "ok");
+    }
+
+    // timing: interleaved rounds
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    const int reps = 5;
+    std::vector<std::vector<float>> ms(vars.size());
+    for (size_t vi = 0; vi < vars.size(); ++vi) { vars[vi].launch(p, grid); vars[vi].launch(p, grid); }
+    HIP_CHECK(hipDeviceSynchronize());
+    for (int r = 0; r < rounds; ++r)
+        for (size_t vi = 0; vi < vars.size(); ++vi) {
+            HIP_CHECK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < reps; ++i) vars[vi].launch(p, grid);
+            HIP_CHECK(hipEventRecord(e1, nullptr));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float t;
+            HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+            ms[vi].push_back(t / reps);
+        }
+    {   // segment stamps of the STAMP variant (if it ran): average cycles per tile per wave
+        std::vector<unsigned long long> h((size_t)grid * 64);
+        HIP_CHECK(hipMemcpy(h.data(), ddbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double seg[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (size_t i = 0; i < (size_t)grid * 8; ++i)
+            for (int k = 0; k < 7; ++k) seg[k] += (double)h[i * 8 + k];
+        if (seg[6] > 0) {
+            const char* nm[6] = {"issue stage loads (v3 only)", "phase A (QK^T + exp)", "phase B (PV + max)", "max update/rescale",
+                                 "stage write (vmcnt+ds_write)", "barrier"};
+            double tot = 0;
+            for (int k = 0; k < 6; ++k) tot += seg[k] / seg[6];
+            printf("  STAMP build: cycles per tile per wave (avg over %.0f wave-tiles), each stamp costs ~40-60:\n", seg[6]);
+            for (int k = 0; k < 6; ++k) printf("      %-30s %8.1f  (%4.1f%%)\n", nm[k], seg[k] / seg[6], 100.0 * seg[k] / seg[6] / tot);
+            printf("      %-30s %8.1f\n", "total", tot);
+        }
+    }
+    const double flops = (causal ? 2.0 : 4.0) * BH * (double)S * S * d;
+    for (size_t vi = 0; vi < vars.size(); ++vi) {
+        std::sort(ms[vi].begin(), ms[vi].end());
+        const double med = ms[vi][ms[vi].size() / 2], mn = ms[vi][0];
+        printf("  [%zu] %-32s med %.4f ms  min %.4f ms  %.1f TFLOP/s (%.1f%% of peak)  best %.1f\n", vi, vars[vi].name.c_str(), med,
+               mn, flops / med / 1e9, 100.0 * flops / med / 1e9 / 2516.6, flops / mn / 1e9);
+    }
+    return 0;
+}
