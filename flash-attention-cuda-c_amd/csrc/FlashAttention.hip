@@ -11,8 +11,7 @@
 
 #include "../../include/flash_attention.h"
 #include "../helpers.hpp"
-#include "kernel_bf16.hip.h"
-#include "kernel_bf16_v1.hip.h"
+#include "kernel_bf16_v4.hip.h"
 #include "generic.hip.h"
 
 namespace fa {
@@ -75,7 +74,7 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
         plan->q_block_rows = calculateSizeBlockQ(d, dtype);
         plan->kv_block_rows = calculateSizeBlockKV(d, dtype);
         plan->threads = 512;
-        plan->lds_bytes = 2 * 2 * plan->kv_block_rows * d * 2;
+        plan->lds_bytes = 3 * 2 * plan->kv_block_rows * d * 2;   // 3-slot ring of [K image | V image]
         const int nQ = getNumCta(S, plan->q_block_rows);
         const int64_t units = (int64_t)B * H * nQ;
         plan->grid = (int)(8 * ((units + 7) / 8));
@@ -92,16 +91,22 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
     return FA_OK;
 }
 
+// The bf16 kernel needs 96 KiB (d = 128) of dynamic LDS: above the 64 KiB default, so the limit is
+// raised once per instantiation (function-local static: thread-safe, not a stream operation).
+template <class Cfg>
+static hipError_t launch_v4(const Params& p, const fa_launch_plan& plan, hipStream_t st) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)fwd_bf16_v4_kernel<Cfg>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * KVStage<Cfg::D>::TILE_BYTES);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((fwd_bf16_v4_kernel<Cfg>), dim3(plan.grid), dim3(plan.threads), plan.lds_bytes, st, p);
+    return hipGetLastError();
+}
+
 template <int D, bool CAUSAL>
 static hipError_t launch_bf16(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
-    dim3 grid(plan.grid), block(plan.threads);
-    if (o_dtype == FA_DTYPE_F32)
-        hipLaunchKernelGGL((fwd_bf16_kernel<D, CAUSAL, float>), grid, block, plan.lds_bytes, st, p);
-    else if (o_dtype == FA_DTYPE_BF16)
-        hipLaunchKernelGGL((fwd_bf16_kernel<D, CAUSAL, __bf16>), grid, block, plan.lds_bytes, st, p);
-    else
-        hipLaunchKernelGGL((fwd_bf16_kernel<D, CAUSAL, _Float16>), grid, block, plan.lds_bytes, st, p);
-    return hipGetLastError();
+    if (o_dtype == FA_DTYPE_F32) return launch_v4<V4Cfg<D, CAUSAL, float>>(p, plan, st);
+    if (o_dtype == FA_DTYPE_BF16) return launch_v4<V4Cfg<D, CAUSAL, __bf16>>(p, plan, st);
+    return launch_v4<V4Cfg<D, CAUSAL, _Float16>>(p, plan, st);
 }
 
 template <typename InT, typename OutT>
@@ -131,11 +136,18 @@ static int run(const void* Q, const void* K, const void* V, void* O, int B, int 
         return FA_ERR_BAD_STRIDE;
     fa_launch_plan plan;
     make_plan(B, H, S, d, causal, dtype, o_dtype, scale, &plan);
+    if (plan.kernel_id == 1) {
+        // K/V are fetched through buffer descriptors with 32-bit byte offsets: one head's extent
+        // (seqLen x row stride) must stay below 2^31 bytes (two prefetch tiles of slack included)
+        const int64_t ks = sK ? sK->strideS : d, vs = sV ? sV->strideS : d;
+        if (((int64_t)S + 192) * ks * 2 >= (1ll << 31) || ((int64_t)S + 192) * vs * 2 >= (1ll << 31)) return FA_ERR_BAD_SHAPE;
+    }
     Params p;
     fill_params(p, Q, K, V, O, B, H, S, d, scale, sQ, sK, sV, sO);
     p.nQ = getNumCta(S, plan.q_block_rows);
     p.units = B * H * p.nQ;
     p.cpx = (p.units + 7) / 8;
+    p.dbg = nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
     if (plan.kernel_id == 1) {

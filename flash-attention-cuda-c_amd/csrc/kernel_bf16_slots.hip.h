@@ -75,6 +75,7 @@ struct SlotWave : PipelinedWave<C> {
         if constexpr (E & 1) {
             sum_b += p;
             pw[E >> 1] = pack_bf16(p_even, p);
+            asm volatile("" : "+v"(sum_a), "+v"(sum_b));   // keep the adds in this slot (hipcc sinks them)
         } else {
             sum_a += p;
             p_even = p;

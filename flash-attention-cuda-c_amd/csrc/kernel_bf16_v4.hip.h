@@ -27,8 +27,10 @@
 namespace fa {
 
 template <int D_, bool CAUSAL_, typename OutT_, int THR_ = 8, int NPRE_ = 4, int VPRE_ = 2, bool STAMP_ = false,
-          int PRIO_ = 0>
+          int PRIO_ = 0, bool OPTIMISTIC_ = true>
 struct V4Cfg {
+    // true: optimistic pass (no per-tile max) + finiteness check + tracked fallback; false: tracked pass only
+    static constexpr bool OPTIMISTIC = OPTIMISTIC_;
     static constexpr int D = D_;
     static constexpr bool CAUSAL = CAUSAL_;
     using OutT = OutT_;
@@ -104,7 +106,7 @@ struct V4Wave : SlotWave<C> {
     using Stage = BufStage<D>;
     static constexpr int NL = Stage::NL;
 
-    bool need;   // lazy-rescale decision for S(t+1), computed in the middle of phase B
+    bool need;   // lazy-rescale decision for S(t+1), computed in the middle of phase B (tracked pass)
 
     // max3 chain over PER values of S(t+1) in slot J (J < NB/2)
     template <int J>
@@ -145,7 +147,7 @@ struct V4Wave : SlotWave<C> {
         }
     }
 
-    template <int J>
+    template <bool TRACK, int J>
     __device__ __forceinline__ void slots_b(const Stage& st, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
                                             const f32x16& c0, const f32x16& c1, const f32x16& n0, const f32x16& n1) {
         if constexpr (J < NB) {
@@ -155,15 +157,18 @@ struct V4Wave : SlotWave<C> {
                 this->vf[JN % (VPRE + 1)] = this->v_frag(v_cur, vbase, JN / DB, JN % DB);
             }
             this->template exp_slot<NA + J>(c0, c1, c);
-            if constexpr (J < NB / 2) max3_slot<J>(n0, n1);
-            if constexpr (J == NB / 2) decide(c);
+            if constexpr (TRACK && J < NB / 2) max3_slot<J>(n0, n1);
+            if constexpr (TRACK && J == NB / 2) decide(c);
             if constexpr (J >= NB / 2 && ((J - NB / 2) & 1) == 0 && (J - NB / 2) / 2 < NL)
                 st.template write<(J - NB / 2) / 2>(wr_slot);
             __builtin_amdgcn_sched_barrier(0);
-            slots_b<J + 1>(st, wr_slot, v_cur, vbase, c, c0, c1, n0, n1);
+            slots_b<TRACK, J + 1>(st, wr_slot, v_cur, vbase, c, c0, c1, n0, n1);
         }
     }
 
+    // One tile.  TRACK = true: running row max with lazy rescale (always safe).  TRACK = false: the
+    // optimistic pass -- m stays the row max of tile 0 and no max / decision / rescale is issued.
+    template <bool TRACK>
     __device__ __forceinline__ void v4_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
                                             int kbase, int vbase, float c, const f32x16& cur0, const f32x16& cur1,
                                             f32x16& nxt0, f32x16& nxt1, bool has_next, bool mask_next, int kv0_next,
@@ -177,14 +182,22 @@ struct V4Wave : SlotWave<C> {
         __builtin_amdgcn_sched_barrier(0);
         slots_a<0>(st, t_load, k_next, v_cur, kbase, vbase, c, cur0, cur1, nxt0, nxt1);
         if constexpr (C::STAMP) this->t_mid = this->stamp();
-        slots_b<0>(st, wr_slot, v_cur, vbase, c, cur0, cur1, nxt0, nxt1);
+        slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur0, cur1, nxt0, nxt1);
         if constexpr (C::STAMP) this->t_end = this->stamp();
         this->l += this->sum_a + this->sum_b;
-        if (has_next) {
-            if (mask_next) {   // diagonal / ragged tile: redo the max on the masked scores (rare)
-                this->mask(nxt0, nxt1, kv0_next, q_row0, S, lane);
-                this->update_max(this->row_max(nxt0, nxt1), c);
-            } else if (need) {
+        // ONE rescale site: the masked (diagonal / ragged) tile only recomputes the scalar decision and the
+        // row max.  (Two sites that both multiply O made hipcc copy all 64 accumulator registers twice
+        // per tile on the common path.)
+        if (has_next && mask_next) {
+            this->mask(nxt0, nxt1, kv0_next, q_row0, S, lane);
+            if constexpr (TRACK) {
+                this->mx_a = this->row_max(nxt0, nxt1);
+                this->mx_b = this->mx_a;
+                decide(c);
+            }
+        }
+        if constexpr (TRACK) {
+            if (has_next && need) {
                 const float mn = fmaxf(this->m, this->mx_a);
                 const float alpha = fast_exp2(this->m - mn);
                 this->m = mn;
@@ -196,7 +209,79 @@ struct V4Wave : SlotWave<C> {
             }
         }
     }
+
+    // True iff this lane's row sum or any of its O accumulators is inf / NaN (x*0 is NaN for both).
+    __device__ __forceinline__ bool not_finite() const {
+        float acc = this->l * 0.f;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc = fmaf(this->o[i][r], 0.f, acc);
+        return acc != acc;
+    }
 };
+
+// One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether
+// the result has to be recomputed with max tracking (only ever true for TRACK = false).
+template <class C, bool TRACK>
+__device__ __forceinline__ bool v4_pass(const Params& p, V4Wave<C>& w, BufStage<C::D>& st, lds_ptr smem, int n_tiles,
+                                        int my_tiles, int q_row0, int wave, int lane, unsigned long long (&acc)[7]) {
+    constexpr int D = C::D;
+    constexpr bool CAUSAL = C::CAUSAL;
+    constexpr int KVBLK = 64;
+    constexpr int TILE = KVStage<D>::TILE_BYTES, SLOT = 2 * TILE;
+    const int S = p.S;
+    w.init();
+    st.load_all(0);
+    st.write_all(smem);
+    st.load_all(1);              // past-the-end tiles read as zeros (buffer range check)
+    st.write_all(smem + SLOT);
+    __syncthreads();
+
+    const int kbase = k_read_base(lane);
+    const int vbase = v_read_base(lane);
+    const float c = p.scale_log2;
+    auto needs_mask = [&](int t) { return (CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > S); };
+
+    f32x16 sA0, sA1, sB0, sB1;
+    if (my_tiles > 0) {
+        w.qk(smem, kbase, sA0, sA1);
+        if (needs_mask(0)) w.mask(sA0, sA1, 0, q_row0, S, lane);
+        w.update_max(w.row_max(sA0, sA1), c);   // m = row max of tile 0 (the reference of the optimistic pass)
+    }
+
+    int so_cur = 0, so_nxt = SLOT, so_wr = 2 * SLOT;
+    auto step = [&](int t, f32x16& cur0, f32x16& cur1, f32x16& nxt0, f32x16& nxt1) {
+        unsigned long long t0 = 0, t4 = 0, t6 = 0;
+        if constexpr (C::STAMP) t0 = w.stamp();
+        if (t < my_tiles) {
+            const bool has_next = t + 1 < my_tiles;
+            w.template v4_step<TRACK>(st, t + 2, smem + so_wr, smem + so_nxt, smem + so_cur + TILE, kbase, vbase, c, cur0,
+                                      cur1, nxt0, nxt1, has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S,
+                                      lane);
+        } else {
+            // wave already past its causal diagonal: it still stages its share of the tile
+            st.load_all(t + 2);
+            st.write_all(smem + so_wr);
+        }
+        if constexpr (C::STAMP) t4 = w.stamp();
+        __syncthreads();
+        if constexpr (C::STAMP) {
+            t6 = w.stamp();
+            acc[1] += w.t_mid - t0; acc[2] += w.t_end - w.t_mid; acc[3] += t4 - w.t_end; acc[5] += t6 - t4; acc[6] += 1;
+        }
+        const int tmp = so_cur;
+        so_cur = so_nxt;
+        so_nxt = so_wr;
+        so_wr = tmp;
+    };
+    for (int t = 0; t < n_tiles; t += 2) {
+        step(t, sA0, sA1, sB0, sB1);
+        if (t + 1 < n_tiles) step(t + 1, sB0, sB1, sA0, sA1);
+    }
+    if constexpr (TRACK) return false;
+    else return __syncthreads_or(my_tiles > 0 && w.not_finite()) != 0;
+}
 
 template <class C>
 __global__ __launch_bounds__(512, 2) void fwd_bf16_v4_kernel(const Params p) {
@@ -205,7 +290,6 @@ __global__ __launch_bounds__(512, 2) void fwd_bf16_v4_kernel(const Params p) {
     using OutT = typename C::OutT;
     using Stage = BufStage<D>;
     constexpr int KVBLK = 64, QBLK = 256;
-    constexpr int TILE = KVStage<D>::TILE_BYTES, SLOT = 2 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     lds_ptr smem = (lds_ptr)smem_raw;
 
@@ -233,61 +317,21 @@ __global__ __launch_bounds__(512, 2) void fwd_bf16_v4_kernel(const Params p) {
     }
 
     V4Wave<C> w;
-    w.init();
     w.load_q(Qh, qSb, q_row0, S, lane);
-
+    w.pin_q();
     Stage st;
     st.init(Kh, Vh, kSb, vSb, S, wave, lane);
-    st.load_all(0);
-    st.write_all(smem);
-    st.load_all(1);              // past-the-end tiles read as zeros (buffer range check)
-    st.write_all(smem + SLOT);
-    w.pin_q();
-    __syncthreads();
-
-    const int kbase = k_read_base(lane);
-    const int vbase = v_read_base(lane);
-    const float c = p.scale_log2;
-
-    auto needs_mask = [&](int t) { return (CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > S); };
-
-    f32x16 sA0, sA1, sB0, sB1;
-    if (my_tiles > 0) {
-        w.qk(smem, kbase, sA0, sA1);
-        if (needs_mask(0)) w.mask(sA0, sA1, 0, q_row0, S, lane);
-        w.update_max(w.row_max(sA0, sA1), c);
-    }
-
-    int so_cur = 0, so_nxt = SLOT, so_wr = 2 * SLOT;
     unsigned long long acc[7] = {0, 0, 0, 0, 0, 0, 0};
 
-    auto step = [&](int t, f32x16& cur0, f32x16& cur1, f32x16& nxt0, f32x16& nxt1) {
-        unsigned long long t0 = 0, t4 = 0, t6 = 0;
-        if constexpr (C::STAMP) t0 = w.stamp();
-        if (t < my_tiles) {
-            const bool has_next = t + 1 < my_tiles;
-            w.v4_step(st, t + 2, smem + so_wr, smem + so_nxt, smem + so_cur + TILE, kbase, vbase, c, cur0, cur1, nxt0, nxt1,
-                      has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
-        } else {
-            // wave already past its causal diagonal: it still stages its share of the tile
-            st.load_all(t + 2);
-            st.write_all(smem + so_wr);
-        }
-        if constexpr (C::STAMP) t4 = w.stamp();
-        __syncthreads();
-        if constexpr (C::STAMP) {
-            t6 = w.stamp();
-            acc[1] += w.t_mid - t0; acc[2] += w.t_end - w.t_mid; acc[3] += t4 - w.t_end; acc[5] += t6 - t4; acc[6] += 1;
-        }
-        const int tmp = so_cur;
-        so_cur = so_nxt;
-        so_nxt = so_wr;
-        so_wr = tmp;
-    };
-
-    for (int t = 0; t < n_tiles; t += 2) {
-        step(t, sA0, sA1, sB0, sB1);
-        if (t + 1 < n_tiles) step(t + 1, sB0, sB1, sA0, sA1);
+    if constexpr (C::OPTIMISTIC) {
+        // Optimistic pass: exponentials relative to the row max of tile 0, no per-tile max tracking.
+        // exp2 / bf16 / f32 accumulation have ~2^127 of headroom above that reference; if a later score
+        // exceeds it (or P.V overflows) l or O becomes inf/NaN, which the check at the end of the pass
+        // catches, and the whole workgroup redoes its block with the tracked (always safe) pass.
+        if (v4_pass<C, false>(p, w, st, smem, n_tiles, my_tiles, q_row0, wave, lane, acc))
+            v4_pass<C, true>(p, w, st, smem, n_tiles, my_tiles, q_row0, wave, lane, acc);
+    } else {
+        v4_pass<C, true>(p, w, st, smem, n_tiles, my_tiles, q_row0, wave, lane, acc);
     }
 
     if constexpr (C::STAMP) {

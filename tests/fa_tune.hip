@@ -18,6 +18,7 @@
 #include "../flash-attention-cuda-c_amd/csrc/kernel_bf16.hip.h"
 #include "../flash-attention-cuda-c_amd/csrc/kernel_bf16_slots.hip.h"
 #include "../flash-attention-cuda-c_amd/csrc/kernel_bf16_v4.hip.h"
+#include "../flash-attention-cuda-c_amd/csrc/kernel_bf16_v5.hip.h"
 #include "../flash-attention-cuda-c_amd/csrc/kernel_bf16_v1.hip.h"
 #include "../oracle/cpu_attention.h"
 
@@ -38,13 +39,13 @@ static inline uint64_t mix(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
     return z ^ (z >> 31);
 }
-static void fill_randn_bf16(std::vector<uint16_t>& v, uint64_t seed) {
+static void fill_randn_bf16(std::vector<uint16_t>& v, uint64_t seed, double mul = 1.0) {
     for (size_t i = 0; i < v.size(); i += 2) {
         const uint64_t a = mix(seed * 0x9e3779b1ull + i), b = mix(seed * 0x85ebca6bull + i + 1);
         const double u1 = ((a >> 11) + 1.0) / 9007199254740993.0, u2 = (b >> 11) / 9007199254740992.0;
         const double r = std::sqrt(-2.0 * std::log(u1));
-        v[i] = oracle_f32_to_bf16((float)(r * std::cos(6.283185307179586 * u2)));
-        if (i + 1 < v.size()) v[i + 1] = oracle_f32_to_bf16((float)(r * std::sin(6.283185307179586 * u2)));
+        v[i] = oracle_f32_to_bf16((float)(mul * r * std::cos(6.283185307179586 * u2)));
+        if (i + 1 < v.size()) v[i + 1] = oracle_f32_to_bf16((float)(mul * r * std::sin(6.283185307179586 * u2)));
     }
 }
 
@@ -83,6 +84,16 @@ static void launch_v4(const Params& p, int grid) {
     (void)once;
     hipLaunchKernelGGL((fwd_bf16_v4_kernel<K>), dim3(grid), dim3(512), lds, nullptr, p);
 }
+template <class K>
+static void launch_v5(const Params& p0, int) {
+    Params p = p0;
+    constexpr int QBLK = 32 * K::NW;
+    p.nQ = (p.S + QBLK - 1) / QBLK;
+    p.units = p.B * p.H * p.nQ;
+    p.cpx = (p.units + 7) / 8;
+    constexpr int lds = 4 * KVStage<K::D>::TILE_BYTES;
+    hipLaunchKernelGGL((fwd_bf16_v5_kernel<K>), dim3(8 * p.cpx), dim3(64 * K::NW), lds, nullptr, p);
+}
 template <int D, bool CAUSAL>
 static void launch_v1(const Params& p, int grid) {
     constexpr int lds = 2 * 2 * KVStage<D>::TILE_BYTES;
@@ -93,22 +104,22 @@ template <int D, bool CAUSAL>
 static std::vector<Variant> make_variants() {
     std::vector<Variant> v;
     v.push_back({"v1 2-slot unpipelined", launch_v1<D, CAUSAL>});
-    v.push_back({"v2 nosched", launch_pipelined<KernelCfg<D, CAUSAL, __bf16, 8, 8, 4, false>>});
-    v.push_back({"v3 slots npre4 vpre2", launch_slots<SlotCfg<D, CAUSAL, __bf16, 8, 4, 2>>});
-    v.push_back({"v4 npre4 vpre2", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 4, 2>>});
-    v.push_back({"v4 npre4 vpre2 prio1", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 4, 2, false, 1>>});
-    v.push_back({"v4 npre6 vpre3", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 6, 3>>});
-    v.push_back({"v4 npre4 vpre2 STAMP", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 4, 2, true>>});
+    v.push_back({"v4 tracked only", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 4, 2, false, 0, false>>});
+    v.push_back({"v4 optimistic+fallback", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 4, 2, false, 0, true>>});
+    v.push_back({"v4 optimistic npre6 vpre3", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 6, 3, false, 0, true>>});
+    v.push_back({"v4 optimistic STAMP", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 4, 2, true, 0, true>>});
     return v;
 }
 
 int main(int argc, char** argv) {
     int B = 8, H = 16, S = 4096, d = 128, causal = 0, rounds = 7;
+    double qkscale = 1.0;   // multiplies Q and K: 12 makes later tiles exceed the tile-0 row max by > 2^127 (fallback path)
     std::vector<int> only;
     std::vector<int> pos;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--rounds" && i + 1 < argc) rounds = atoi(argv[++i]);
+        else if (a == "--qkscale" && i + 1 < argc) qkscale = atof(argv[++i]);
         else if (a == "--only" && i + 1 < argc) {
             char* s = argv[++i];
             for (char* t = strtok(s, ","); t; t = strtok(nullptr, ",")) only.push_back(atoi(t));
@@ -119,7 +130,7 @@ int main(int argc, char** argv) {
     const size_t per_head = (size_t)S * d, n = per_head * BH;
     const int distinct = std::min(BH, 8);
     std::vector<uint16_t> hq(per_head * distinct), hk(per_head * distinct), hv(per_head * distinct);
-    fill_randn_bf16(hq, 1); fill_randn_bf16(hk, 2); fill_randn_bf16(hv, 3);
+    fill_randn_bf16(hq, 1, qkscale); fill_randn_bf16(hk, 2, qkscale); fill_randn_bf16(hv, 3);
     void *dq, *dk, *dv, *dref, *dout;
     HIP_CHECK(hipMalloc(&dq, n * 2)); HIP_CHECK(hipMalloc(&dk, n * 2)); HIP_CHECK(hipMalloc(&dv, n * 2));
     HIP_CHECK(hipMalloc(&dref, n * 2)); HIP_CHECK(hipMalloc(&dout, n * 2));
@@ -167,7 +178,7 @@ int main(int argc, char** argv) {
         }
     };
     std::vector<uint16_t> out0(n), outv(n);
-    printf("problem: B=%d H=%d S=%d d=%d causal=%d  grid=%d  rounds=%d\n", B, H, S, d, causal, grid, rounds);
+    printf("problem: B=%d H=%d S=%d d=%d causal=%d  grid=%d  rounds=%d qkscale=%g\n", B, H, S, d, causal, grid, rounds, qkscale);
     for (size_t vi = 0; vi < vars.size(); ++vi) {
         HIP_CHECK(hipMemset(dout, 0xff, n * 2));
         vars[vi].launch(p, grid);

@@ -79,6 +79,8 @@ def test_launch_plan(B, H, S, d, causal, dtype, kid, br, bc):
     units = B * H * n_q
     assert p["grid"] == 8 * (-(-units // 8)) and p["grid"] >= units
     assert p["threads"] % 64 == 0 and p["lds_bytes"] <= 160 * 1024
+    if kid == 1:
+        assert p["lds_bytes"] == 3 * 2 * 64 * d * 2      # 3-slot ring of K+V tiles
 
 
 def test_no_cpu_fallback_in_binding():

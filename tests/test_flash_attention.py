@@ -167,6 +167,25 @@ def test_large_score_range_no_overflow():
     check(run_gpu(Q, K, V, False), ref, 8e-3, 8e-3)
 
 
+@pytest.mark.parametrize("d,causal", [(128, True), (64, False)])
+def test_optimistic_pass_falls_back_to_tracked_max(d, causal):
+    """The bf16 kernel first runs an optimistic pass (exponentials relative to the row max of the FIRST
+    key tile, no per-tile max).  Q, K x12 makes later tiles exceed that reference by more than 2^127, so
+    the pass produces inf/NaN, its finiteness check fires and the workgroup recomputes with max tracking.
+    A second case keeps the excess below 2^127 (P up to ~2^100 in the optimistic pass, no fallback)."""
+    B, H, S = 1, 3, 1536
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in (50, 51, 52))
+    for mul in (12.0, 4.0):
+        Qm, Km = (Q.float() * mul).to(torch.bfloat16), (K.float() * mul).to(torch.bfloat16)
+        ref = oracle.attention(Qm.float().numpy(), Km.float().numpy(), V.float().numpy(), causal=causal)
+        check(run_gpu(Qm, Km, V, causal), ref, 1.6e-2, 1.6e-2)
+    # spike far beyond 2^127 at one (row, key) pair in the middle of the sequence
+    K2 = K.clone()
+    K2[:, :, 900] = (12.0 * Q[:, :, 1000].float()).to(torch.bfloat16)
+    ref = oracle.attention(Q.float().numpy(), K2.float().numpy(), V.float().numpy(), causal=causal)
+    check(run_gpu(Q, K2, V, causal), ref, 4e-3, 4e-3, rms=1e-3)
+
+
 def test_heads_are_independent():
     """Reference defect D2 (every query attends to every batch/head) must not be reproduced:
     a head computed alone equals the same head computed inside a batch, bit for bit."""
