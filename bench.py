@@ -161,7 +161,7 @@ def main():
             "output_ok": ok_all,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "kernel": "fa::fwd_bf16_kernel", "kernel_ms": round(kernel_ms_max, 5),
+                         "kernel": "fa::fwd_bf16_v4_kernel", "kernel_ms": round(kernel_ms_max, 5),
                          "algorithmic_hbm_bytes": 4 * heads_local * S * d * 2,
                          "algorithmic_hbm_GBps": round(4 * heads_local * S * d * 2 / (kernel_ms_max * 1e-3) / 1e9, 1)},
         }
