@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- forward attention TFLOP/s on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg2nc|cfg1|cfg4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg2nc|cfg1|cfg3|cfg4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -35,6 +35,7 @@ WORKLOADS = {
     "cfg2nc": (8, 16, 4096, 128, False, "BASELINE cfg2 shape, non-causal: bf16 B=8 H=16 S=4096 d=128"),
     "cfg1": (4, 8, 2048, 64, False, "BASELINE cfg1: bf16 B=4 H=8 S=2048 d=64 non-causal"),
     "cfg4": (64, 32, 8192, 128, False, "BASELINE cfg4: bf16 B=64 H=32 S=8192 d=128, B*H sharded over the ranks"),
+    "cfg3": (1, 16, 16384, 128, False, "BASELINE cfg3: fp8 e4m3fn B=1 H=16 S=16384 d=128 non-causal (B, H chosen: unspecified)"),
 }
 
 
@@ -107,7 +108,8 @@ def main():
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     shape = (heads_local, 1, S, d)   # the rank's slab as a dense [heads,1,S,d] tensor
-    Q, K, V = (torch.randn(shape, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(3))
+    in_dtype = torch.float8_e4m3fn if args.workload == "cfg3" else torch.bfloat16
+    Q, K, V = (torch.randn(shape, generator=g, device=dev, dtype=torch.float32).to(in_dtype) for _ in range(3))
     O = torch.empty(shape, device=dev, dtype=torch.bfloat16 if args.out_dtype == "bf16" else torch.float32)
     scale = 1.0 / d ** 0.5
 
@@ -152,7 +154,8 @@ def main():
                       else "fwd attention TFLOP/s",
             "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": scaling, "vs_baseline": None, "dtype": "fp8_e4m3fn" if args.workload == "cfg3" else "bf16",
+            "data": "synthetic",
             "config": {"workload": desc, "B": B, "H": H, "S": S, "d": d, "causal": causal,
                        "out_dtype": args.out_dtype, "heads_per_gpu": heads_local,
                        "flop_convention": "2*B*H*S^2*d causal / 4*B*H*S^2*d non-causal",
@@ -161,9 +164,10 @@ def main():
             "output_ok": ok_all,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "kernel": "fa::fwd_bf16_v4_kernel", "kernel_ms": round(kernel_ms_max, 5),
-                         "algorithmic_hbm_bytes": 4 * heads_local * S * d * 2,
-                         "algorithmic_hbm_GBps": round(4 * heads_local * S * d * 2 / (kernel_ms_max * 1e-3) / 1e9, 1)},
+                         "kernel": "fa::fwd_mfma_kernel", "kernel_ms": round(kernel_ms_max, 5),
+                         "algorithmic_hbm_bytes": heads_local * S * d * (3 * Q.element_size() + O.element_size()),
+                         "algorithmic_hbm_GBps": round(heads_local * S * d * (3 * Q.element_size() + O.element_size())
+                                                       / (kernel_ms_max * 1e-3) / 1e9, 1)},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(S, d, causal)

@@ -97,6 +97,16 @@ def _dtype_code(t):
     return table[t]
 
 
+def _default_out_dtype(in_dtype):
+    """fp32 in -> fp32 out (the reference's float* O); fp8 in -> bf16 out; otherwise the input type."""
+    import torch
+    if in_dtype == torch.float32:
+        return torch.float32
+    if in_dtype == getattr(torch, "float8_e4m3fn", None):
+        return torch.bfloat16
+    return in_dtype
+
+
 def _stream_ptr(stream):
     import torch
     s = stream if stream is not None else torch.cuda.current_stream()
@@ -130,8 +140,7 @@ def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None
     if scale is None:
         scale = 1.0 / float(d) ** 0.5
     if O is None:
-        O = torch.empty((B, H, S, d), dtype=out_dtype or (torch.float32 if Q.dtype == torch.float32 else Q.dtype),
-                        device=Q.device)
+        O = torch.empty((B, H, S, d), dtype=out_dtype or _default_out_dtype(Q.dtype), device=Q.device)
     elif O.shape != Q.shape or not O.is_cuda:
         raise ValueError("O must be a device tensor shaped like Q")
     dense = all(t.is_contiguous() for t in (Q, K, V, O))
@@ -171,8 +180,7 @@ def multi_head_attention(Q, K, V, num_heads, is_causal=False, return_attn=False,
     if dm % num_heads != 0:
         raise ValueError("d_model must be divisible by num_heads")
     dk = dm // num_heads                                                 # check.py:11
-    out = torch.empty((B, S, dm), device=Q.device,
-                      dtype=out_dtype or (torch.float32 if Q.dtype == torch.float32 else Q.dtype))
+    out = torch.empty((B, S, dm), device=Q.device, dtype=out_dtype or _default_out_dtype(Q.dtype))
     view = lambda t: t.view(B, S, num_heads, dk).transpose(1, 2)         # check.py:14-16 (views only)
     flash_attention(view(Q), view(K), view(V), view(out), scale=1.0 / float(dk) ** 0.5, is_causal=is_causal)
     return out, None

@@ -11,7 +11,7 @@
 
 #include "../../include/flash_attention.h"
 #include "../helpers.hpp"
-#include "kernel_bf16_v4.hip.h"
+#include "kernel_bf16.hip.h"
 #include "generic.hip.h"
 
 namespace fa {
@@ -58,9 +58,10 @@ static int validate(const void* Q, const void* K, const void* V, void* O, int B,
     if (B <= 0 || H <= 0 || S <= 0 || d <= 0) return FA_ERR_BAD_SHAPE;
     if ((int64_t)B * H > INT32_MAX / 2 || S > (1 << 24)) return FA_ERR_BAD_SHAPE;
     if (!std::isfinite(scale)) return FA_ERR_BAD_SCALE;
-    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16) return FA_ERR_UNSUPPORTED_DTYPE;
+    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP8_E4M3) return FA_ERR_UNSUPPORTED_DTYPE;
     if (o_dtype != FA_DTYPE_F32 && o_dtype != FA_DTYPE_BF16 && o_dtype != FA_DTYPE_F16) return FA_ERR_UNSUPPORTED_DTYPE;
     if (d > 256) return FA_ERR_UNSUPPORTED_DHEAD;
+    if (dtype == FA_DTYPE_FP8_E4M3 && (d != 128 || !(scale > 0.f))) return FA_ERR_UNSUPPORTED_DHEAD;   // fp8: MFMA path only
     if ((d * elem_size(dtype)) % 16 != 0 || (d * elem_size(o_dtype)) % 16 != 0) return FA_ERR_UNSUPPORTED_DHEAD;
     return FA_OK;
 }
@@ -68,13 +69,15 @@ static int validate(const void* Q, const void* K, const void* V, void* O, int B,
 static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_dtype, float scale,
                      fa_launch_plan* plan) {
     (void)causal; (void)o_dtype;
-    const bool mfma = dtype == FA_DTYPE_BF16 && (d == 64 || d == 128) && scale > 0.f;
-    if (mfma) {
-        plan->kernel_id = 1;
+    const bool mfma_bf16 = dtype == FA_DTYPE_BF16 && (d == 64 || d == 128) && scale > 0.f;
+    const bool mfma_fp8 = dtype == FA_DTYPE_FP8_E4M3 && d == 128 && scale > 0.f;
+    if (mfma_bf16 || mfma_fp8) {
+        plan->kernel_id = mfma_fp8 ? 2 : 1;
         plan->q_block_rows = calculateSizeBlockQ(d, dtype);
         plan->kv_block_rows = calculateSizeBlockKV(d, dtype);
         plan->threads = 512;
-        plan->lds_bytes = 3 * 2 * plan->kv_block_rows * d * 2;   // 3-slot ring of [K image | V image]
+        // 3-slot ring of [K image (input type) | V image (bf16)]
+        plan->lds_bytes = 3 * plan->kv_block_rows * d * ((mfma_fp8 ? 1 : 2) + 2);
         const int nQ = getNumCta(S, plan->q_block_rows);
         const int64_t units = (int64_t)B * H * nQ;
         plan->grid = (int)(8 * ((units + 7) / 8));
@@ -91,22 +94,22 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
     return FA_OK;
 }
 
-// The bf16 kernel needs 96 KiB (d = 128) of dynamic LDS: above the 64 KiB default, so the limit is
-// raised once per instantiation (function-local static: thread-safe, not a stream operation).
+// The MFMA kernel needs up to 96 KiB of dynamic LDS: above the 64 KiB default, so the limit is raised
+// once per instantiation (function-local static: thread-safe, not a stream operation).
 template <class Cfg>
-static hipError_t launch_v4(const Params& p, const fa_launch_plan& plan, hipStream_t st) {
-    static const hipError_t attr = hipFuncSetAttribute((const void*)fwd_bf16_v4_kernel<Cfg>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * KVStage<Cfg::D>::TILE_BYTES);
+static hipError_t launch_mfma(const Params& p, const fa_launch_plan& plan, hipStream_t st) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)fwd_mfma_kernel<Cfg>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((fwd_bf16_v4_kernel<Cfg>), dim3(plan.grid), dim3(plan.threads), plan.lds_bytes, st, p);
+    hipLaunchKernelGGL((fwd_mfma_kernel<Cfg>), dim3(plan.grid), dim3(plan.threads), Cfg::LDS_BYTES, st, p);
     return hipGetLastError();
 }
 
-template <int D, bool CAUSAL>
-static hipError_t launch_bf16(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
-    if (o_dtype == FA_DTYPE_F32) return launch_v4<V4Cfg<D, CAUSAL, float>>(p, plan, st);
-    if (o_dtype == FA_DTYPE_BF16) return launch_v4<V4Cfg<D, CAUSAL, __bf16>>(p, plan, st);
-    return launch_v4<V4Cfg<D, CAUSAL, _Float16>>(p, plan, st);
+template <int D, bool CAUSAL, int ESZ>
+static hipError_t launch_mfma_out(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
+    if (o_dtype == FA_DTYPE_F32) return launch_mfma<KernelCfg<D, CAUSAL, float, ESZ>>(p, plan, st);
+    if (o_dtype == FA_DTYPE_BF16) return launch_mfma<KernelCfg<D, CAUSAL, __bf16, ESZ>>(p, plan, st);
+    return launch_mfma<KernelCfg<D, CAUSAL, _Float16, ESZ>>(p, plan, st);
 }
 
 template <typename InT, typename OutT>
@@ -136,11 +139,11 @@ static int run(const void* Q, const void* K, const void* V, void* O, int B, int 
         return FA_ERR_BAD_STRIDE;
     fa_launch_plan plan;
     make_plan(B, H, S, d, causal, dtype, o_dtype, scale, &plan);
-    if (plan.kernel_id == 1) {
+    if (plan.kernel_id != 0) {
         // K/V are fetched through buffer descriptors with 32-bit byte offsets: one head's extent
         // (seqLen x row stride) must stay below 2^31 bytes (two prefetch tiles of slack included)
         const int64_t ks = sK ? sK->strideS : d, vs = sV ? sV->strideS : d;
-        if (((int64_t)S + 192) * ks * 2 >= (1ll << 31) || ((int64_t)S + 192) * vs * 2 >= (1ll << 31)) return FA_ERR_BAD_SHAPE;
+        if (((int64_t)S + 192) * ks * esz >= (1ll << 31) || ((int64_t)S + 192) * vs * esz >= (1ll << 31)) return FA_ERR_BAD_SHAPE;
     }
     Params p;
     fill_params(p, Q, K, V, O, B, H, S, d, scale, sQ, sK, sV, sO);
@@ -150,9 +153,11 @@ static int run(const void* Q, const void* K, const void* V, void* O, int B, int 
     p.dbg = nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
-    if (plan.kernel_id == 1) {
-        if (d == 128) e = causal ? launch_bf16<128, true>(p, plan, o_dtype, st) : launch_bf16<128, false>(p, plan, o_dtype, st);
-        else          e = causal ? launch_bf16<64, true>(p, plan, o_dtype, st) : launch_bf16<64, false>(p, plan, o_dtype, st);
+    if (plan.kernel_id == 2) {
+        e = causal ? launch_mfma_out<128, true, 1>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 1>(p, plan, o_dtype, st);
+    } else if (plan.kernel_id == 1) {
+        if (d == 128) e = causal ? launch_mfma_out<128, true, 2>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 2>(p, plan, o_dtype, st);
+        else          e = causal ? launch_mfma_out<64, true, 2>(p, plan, o_dtype, st) : launch_mfma_out<64, false, 2>(p, plan, o_dtype, st);
     } else if (dtype == FA_DTYPE_F32) {
         e = launch_generic<float>(p, plan, d, causal, o_dtype, st);
     } else {
@@ -184,7 +189,8 @@ int flash_attention_plan(int batchSize, int numHeads, int seqLen, int dHead, boo
                          int o_dtype, fa_launch_plan* plan) {
     if (!plan) return FA_ERR_NULL_POINTER;
     if (batchSize <= 0 || numHeads <= 0 || seqLen <= 0 || dHead <= 0) return FA_ERR_BAD_SHAPE;
-    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16) return FA_ERR_UNSUPPORTED_DTYPE;
+    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP8_E4M3) return FA_ERR_UNSUPPORTED_DTYPE;
+    if (dtype == FA_DTYPE_FP8_E4M3 && dHead != 128) return FA_ERR_UNSUPPORTED_DHEAD;
     if (dHead > 256 || (dHead * fa::elem_size(dtype)) % 16 != 0) return FA_ERR_UNSUPPORTED_DHEAD;
     return fa::make_plan(batchSize, numHeads, seqLen, dHead, is_causal, dtype, o_dtype, 1.0f, plan);
 }

@@ -1,323 +1,183 @@
-// kernel_bf16.hip.h -- the bf16 MFMA forward kernel (software-pipelined, 3-slot LDS ring).
+// kernel_bf16.hip.h -- the MFMA forward kernel (bf16 or fp8-e4m3fn inputs, d in {64,128}).
 //
-// Counterpart of the reference's kernel entry kernels/FlashAttention.cuh:59-84 and of the loop
-// nests of kernels/computers.cuh:33-67 / kernels/loaders.cuh:132-156,177-201.  The reference
-// commits a tile and immediately waits for it on every pipeline (no load/compute overlap, SURVEY.md
-// section 3.1); here three things overlap inside every wave:
+// Counterpart of the reference's kernel entry kernels/FlashAttention.cuh:59-84 and of the loop nests of
+// kernels/computers.cuh:33-67 / kernels/loaders.cuh:132-156,177-201.  The reference commits a tile and
+// immediately waits for it on every cuda::pipeline (no load/compute overlap).
 //
-//   iteration t of a wave (tile = 64 keys, the wave owns 32 query rows):
-//     top      issue the global loads of tile t+2 into registers          (HBM/L2 latency)
-//     phase A  S(t+1) = K(t+1).Q^T    MFMA   ||  P(t) = exp2(c*S(t) - m), row sum, ->bf16   VALU
-//     phase B  O^T   += V(t)^T.P(t)^T MFMA   ||  row max of S(t+1), tail of P(t)            VALU
-//     end      lazy rescale decision for tile t+1; write tile t+2 into ring slot (t+2)%3; barrier
+// One workgroup = 8 waves = 256 query rows of one (batch, head); a wave owns 32 rows; KV tiles of 64
+// keys live in a 3-slot LDS ring [K image | V image] (loaders.hip.h).  Iteration t of a wave reads
+// K(t+1) and V(t) and stages tile t+2 into slot (t+2)%3 = slot (t-1)%3, last read in iteration t-1, which
+// every wave left at the previous barrier: ONE barrier per tile.  The loop is unrolled x2 with ping-pong
+// score registers so S(t+1) never has to be copied into S(t).  What happens inside a tile: computers.hip.h.
 //
-//   K(t+1) and V(t) are both live in LDS, hence a 3-slot ring (96 KiB at d = 128): slot (t+2)%3 =
-//   slot (t-1)%3 was last read in iteration t-1, which every wave left at the previous barrier.
-//   One barrier per tile.  The loop is unrolled x2 with ping-pong score registers so S(t+1) never
-//   has to be copied into S(t).
+// Optimistic max.  exp2 / bf16 / f32 accumulation have ~2^127 of headroom, so the first pass takes
+// every exponential relative to the row max of tile 0 and issues no per-tile max, decision or rescale
+// (-4.5 % time).  If a later score exceeds that reference by more than the headroom (or P.V overflows),
+// l or O becomes inf/NaN; each lane tests that at the end of the pass, __syncthreads_or makes it
+// workgroup-uniform, and the whole block is recomputed by the tracked pass (running max, lazy rescale
+// with threshold 2^THR), which is always safe.
 #pragma once
 
 #include "computers.hip.h"
 
 namespace fa {
 
-template <int D_, bool CAUSAL_, typename OutT_, int THR_ = 8, int SPLIT_B_ = 8, int NPRE_ = 4, bool SCHED_ = true,
-          int VALU_A_ = 5, int VALU_B_ = 4>
+template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, bool STAMP_ = false, bool OPTIMISTIC_ = true, int NPRE_ = 4,
+          int VPRE_ = 2, int THR_ = 8>
 struct KernelCfg {
-    static constexpr bool SCHED = SCHED_;     // pin the MFMA / LDS-read / VALU interleave with sched_group_barrier
-    static constexpr int VALU_A = VALU_A_, VALU_B = VALU_B_;   // VALU instructions per MFMA gap in phase A / B
-    static constexpr int NPRE = NPRE_;        // K fragments read ahead of their MFMA
     static constexpr int D = D_;
     static constexpr bool CAUSAL = CAUSAL_;
     using OutT = OutT_;
-    static constexpr int THR = THR_;          // lazy-rescale threshold, log2 units
-    static constexpr int SPLIT_B = SPLIT_B_;  // how many of the 32 exponentials run in phase B
+    static constexpr int ESZ = ESZ_;                 // bytes per Q/K/V element: 2 = bf16, 1 = fp8 e4m3fn
+    static constexpr bool STAMP = STAMP_;            // diagnostic build: s_memtime stamps around the segments
+    static constexpr bool OPTIMISTIC = OPTIMISTIC_;  // optimistic pass + finiteness check + tracked fallback
+    static constexpr int NPRE = NPRE_;               // K fragments in flight ahead of their MFMA
+    static constexpr int VPRE = VPRE_;               // V^T fragments in flight ahead of their MFMA
+    static constexpr int THR = THR_;                 // lazy-rescale threshold of the tracked pass, log2 units
+    static constexpr int LDS_BYTES = 3 * TileGeom<D_, ESZ_>::SLOT;
 };
 
-template <class C>
-struct PipelinedWave {
-    static constexpr int D = C::D;
-    static constexpr int KS = D / 16;
-    static constexpr int DB = D / 32;
-    using Stage = KVStage<D>;
-
-    bf16x8 qf[KS];
-    f32x16 o[DB];
-    float m, l;
-
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int i = 0; i < DB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-        m = -INFINITY;
-        l = 0.f;
-    }
-
-    __device__ __forceinline__ void load_q(const char* Qh, int64_t qS_bytes, int row0, int S, int lane) {
-        int r = row0 + (lane & 31);
-        r = r < S ? r : S - 1;
-        const char* src = Qh + r * qS_bytes + (lane >> 5) * 16;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 32);
-    }
-    // Make the Q fragments look "consumed" so hipcc waits for their loads HERE and not with a
-    // pessimistic vmcnt inside the main loop (where it would also drain the tile prefetch).
-    __device__ __forceinline__ void pin_q() {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            u32x4 t = __builtin_bit_cast(u32x4, qf[ks]);
-            asm volatile("" : "+v"(t));
-            qf[ks] = __builtin_bit_cast(bf16x8, t);
-        }
-    }
-
-    // S^T(both 32-key halves) = K.Q^T from the K image at `kimg`.  K fragments are read through a
-    // rolling NPRE-deep register window (reading all 2*KS ahead costs 64 VGPRs at d = 128 and spills).
-    __device__ __forceinline__ void qk(lds_ptr kimg, int kbase, f32x16& s0, f32x16& s1) const {
-        constexpr int N = 2 * KS, NPRE = C::NPRE < N ? C::NPRE : N;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-        bf16x8 f[NPRE];
-        // fragment i: key half kt = i / KS, k-step ks = i % KS
-#pragma unroll
-        for (int i = 0; i < NPRE; ++i) f[i] = lds_read_b128(kimg, kbase + (i % KS) * 2048 + (i / KS) * 512);
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            if (i < KS) s0 = mfma_32x32x16(f[i % NPRE], qf[i % KS], s0);
-            else        s1 = mfma_32x32x16(f[i % NPRE], qf[i % KS], s1);
-            if (i + NPRE < N)
-                f[i % NPRE] = lds_read_b128(kimg, kbase + ((i + NPRE) % KS) * 2048 + ((i + NPRE) / KS) * 512);
-        }
-    }
-
-    __device__ __forceinline__ void mask(f32x16& s0, f32x16& s1, int kv0, int q_row0, int S, int lane) const {
-        const int qi = q_row0 + (lane & 31);
-        const int lim = C::CAUSAL ? (qi < S - 1 ? qi : S - 1) : S - 1;
-        const int k0 = kv0 + 4 * (lane >> 5);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = (k0 + acc_row(r, 0)) > lim ? -INFINITY : s0[r];
-            s1[r] = (k0 + 32 + acc_row(r, 0)) > lim ? -INFINITY : s1[r];
-        }
-    }
-
-    __device__ __forceinline__ float row_max(const f32x16& s0, const f32x16& s1) const {
-        float a = fmaxf(s0[0], s0[1]), b = fmaxf(s1[0], s1[1]);
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) {
-            a = fmaxf(a, fmaxf(s0[r], s0[r + 1]));
-            b = fmaxf(b, fmaxf(s1[r], s1[r + 1]));
-        }
-        return fmaxf(a, b);
-    }
-
-    // Decide (wave-uniform) whether the running max has to move for a tile whose raw row max is mx.
-    __device__ __forceinline__ void update_max(float mx_raw, float c) {
-        const float mx = max_both_halves(mx_raw) * c;
-        if (__any(mx > m + (float)C::THR)) {
-            const float mn = fmaxf(m, mx);
-            const float alpha = fast_exp2(m - mn);
-            m = mn;
-            l *= alpha;
-#pragma unroll
-            for (int i = 0; i < DB; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        }
-    }
-
-    // p = exp2(c*s - m) for elements [e0, e1) of the 32 scores (0..15 -> s0, 16..31 -> s1); adds the
-    // partial row sums and packs pairs into the PV B-fragments pf[e/8].
-    template <int E0, int E1>
-    __device__ __forceinline__ void exp_range(const f32x16& s0, const f32x16& s1, float c, bf16x8 (&pf)[4],
-                                              float& sum_a, float& sum_b) const {
-#pragma unroll
-        for (int e = E0; e < E1; e += 2) {
-            const float x0 = e < 16 ? s0[e & 15] : s1[e & 15];
-            const float x1 = e < 16 ? s0[(e + 1) & 15] : s1[(e + 1) & 15];
-            const float p0 = fast_exp2(fmaf(x0, c, -m));
-            const float p1 = fast_exp2(fmaf(x1, c, -m));
-            sum_a += p0;
-            sum_b += p1;
-            pf[e >> 3][e & 7] = (__bf16)p0;
-            pf[e >> 3][(e & 7) + 1] = (__bf16)p1;
-        }
-    }
-
-    __device__ __forceinline__ bf16x8 v_frag(lds_ptr vimg, int vbase, int s4, int db) const {
-        const s16x4 lo = lds_read_tr16_b64(vimg, vbase + (2 * s4) * (DB * 512) + db * 512);
-        const s16x4 hi = lds_read_tr16_b64(vimg, vbase + (2 * s4 + 1) * (DB * 512) + db * 512);
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-    }
-
-    template <int S4_0, int S4_1>
-    __device__ __forceinline__ void pv_range(lds_ptr vimg, int vbase, const bf16x8 (&pf)[4]) {
-#pragma unroll
-        for (int s4 = S4_0; s4 < S4_1; ++s4)
-#pragma unroll
-            for (int db = 0; db < DB; ++db) o[db] = mfma_32x32x16(v_frag(vimg, vbase, s4, db), pf[s4], o[db]);
-    }
-
-    // Full pipelined iteration: cur = S(t) (consumed), nxt = S(t+1) (produced).
-    // On the wave's last tile (has_next == false) the QK^T of the non-existent next tile is still
-    // issued -- its result is never looked at -- so that there is ONE hot code path (a separate tail
-    // body doubled the code and pushed lane-constant registers into scratch).
-    __device__ __forceinline__ void full_step(lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase, float c,
-                                              const f32x16& cur0, const f32x16& cur1, f32x16& nxt0, f32x16& nxt1,
-                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S,
-                                              int lane) {
-        constexpr int EA = 32 - C::SPLIT_B;
-        bf16x8 pf[4];
-        float sa = 0.f, sb = 0.f;
-        // phase A
-        qk(k_next, kbase, nxt0, nxt1);
-        exp_range<0, EA>(cur0, cur1, c, pf, sa, sb);
-        // phase B
-        pv_range<0, EA / 8>(v_cur, vbase, pf);
-        exp_range<EA, 32>(cur0, cur1, c, pf, sa, sb);
-        float mx = row_max(nxt0, nxt1);
-        pv_range<EA / 8, 4>(v_cur, vbase, pf);
-        l += sa + sb;
-        if constexpr (C::SCHED) {
-            // Pin the interleave of this basic block (LLVM SchedGroupMask: VALU 0x2, MFMA 0x8,
-            // DS_READ 0x100): K fragments NPRE ahead of their MFMA, ~5 VALU per MFMA gap in phase A
-            // (exp work), V^T fragments two ahead in phase B with the row max of S(t+1).
-            constexpr int NA = 2 * KS, NB = 4 * DB;
-            __builtin_amdgcn_sched_group_barrier(0x100, C::NPRE, 0);
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, C::VALU_A, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, C::VALU_B, 0);
-            }
-        }
-        if (has_next) {
-            if (mask_next) {
-                mask(nxt0, nxt1, kv0_next, q_row0, S, lane);
-                mx = row_max(nxt0, nxt1);
-            }
-            update_max(mx, c);
-        }
-    }
-
-    template <typename OutT>
-    __device__ __forceinline__ void store_o(char* Oh, int64_t oS_bytes, int row0, int S, int lane) {
-        const float inv = 1.0f / sum_both_halves(l);
-        const int qi = row0 + (lane & 31);
-        const int h = lane >> 5;
-        if (qi >= S) return;
-        char* dst = Oh + qi * oS_bytes;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = 32 * db + 8 * g4 + 4 * h;
-                const float a = o[db][4 * g4 + 0] * inv, b = o[db][4 * g4 + 1] * inv;
-                const float c2 = o[db][4 * g4 + 2] * inv, e = o[db][4 * g4 + 3] * inv;
-                if constexpr (sizeof(OutT) == 4) {
-                    f32x4 v = {a, b, c2, e};
-                    *reinterpret_cast<f32x4*>(dst + d0 * 4) = v;
-                } else if constexpr (__is_same(OutT, __bf16)) {
-                    u32x2 v = {pack_bf16(a, b), pack_bf16(c2, e)};
-                    *reinterpret_cast<u32x2*>(dst + d0 * 2) = v;
-                } else {
-                    u32x2 v = {pack_f16(a, b), pack_f16(c2, e)};
-                    *reinterpret_cast<u32x2*>(dst + d0 * 2) = v;
-                }
-            }
-    }
-};
-
-template <class C>
-__global__ __launch_bounds__(512, 2) void fwd_bf16_pipelined_kernel(const Params p) {
-    constexpr int D = C::D;
+// One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the
+// result has to be recomputed with max tracking (only ever true for TRACK = false).
+template <class C, bool TRACK>
+__device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& w, BufStage<C::D, C::ESZ>& st, lds_ptr smem,
+                                               int n_tiles, int my_tiles, int q_row0, int lane,
+                                               unsigned long long (&acc)[12], bool tile0_in_flight) {
+    using G = TileGeom<C::D, C::ESZ>;
     constexpr bool CAUSAL = C::CAUSAL;
-    using OutT = typename C::OutT;
-    using Stage = KVStage<D>;
-    constexpr int KVBLK = 64, QBLK = 256;
-    constexpr int TILE = Stage::TILE_BYTES, SLOT = 2 * TILE;   // slot = [K image | V image]
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    lds_ptr smem = (lds_ptr)smem_raw;
-
-    int g, qb;
-    if (!unit_of_block(p, CAUSAL, g, qb)) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = g / p.H, h = g - b * p.H;
+    constexpr int KVBLK = 64, SLOT = G::SLOT, KT = G::K_TILE;
     const int S = p.S;
-
-    const char* Qh = (const char*)p.Q + (b * p.qB + h * p.qH) * 2;
-    const char* Kh = (const char*)p.K + (b * p.kB + h * p.kH) * 2;
-    const char* Vh = (const char*)p.V + (b * p.vB + h * p.vH) * 2;
-    char* Oh = (char*)p.O + (b * p.oB + h * p.oH) * (int64_t)sizeof(OutT);
-    const int64_t qSb = p.qS * 2, kSb = p.kS * 2, vSb = p.vS * 2, oSb = p.oS * (int64_t)sizeof(OutT);
-
-    const int q_row0 = qb * QBLK + wave * 32;
-    const int q_end = min(S, (qb + 1) * QBLK);
-    const int n_tiles = CAUSAL ? (q_end + KVBLK - 1) / KVBLK : (S + KVBLK - 1) / KVBLK;
-    const bool wave_live = q_row0 < S;
-    const int my_tiles = !wave_live ? 0 : (CAUSAL ? min(n_tiles, (q_row0 + 31) / KVBLK + 1) : n_tiles);
-
-    PipelinedWave<C> w;
+    unsigned long long tp0 = 0, tp1 = 0, tp2 = 0;
+    if constexpr (C::STAMP) tp0 = cycle_stamp();
     w.init();
-    w.load_q(Qh, qSb, q_row0, S, lane);
-
-    Stage st;
-    st.load(Kh, Vh, kSb, vSb, 0, S, wave, lane);
-    st.write(smem, smem + TILE, wave, lane);
-    if (n_tiles > 1) {
-        st.load(Kh, Vh, kSb, vSb, KVBLK, S, wave, lane);
-        st.write(smem + SLOT, smem + SLOT + TILE, wave, lane);
-    }
-    w.pin_q();
-    __syncthreads();
-
     const int kbase = k_read_base(lane);
     const int vbase = v_read_base(lane);
     const float c = p.scale_log2;
-
     auto needs_mask = [&](int t) { return (CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > S); };
-
     f32x16 sA0, sA1, sB0, sB1;
+
+    // Prologue: tile 0 (requested by the caller together with Q on the first pass) -> LDS, barrier; then
+    // tile 1 is fetched while S(0) = K(0).Q^T and its row max are computed.
+    if (!tile0_in_flight) st.load_all(0);
+    st.write_all(smem);
+    __syncthreads();
+    st.load_all(1);          // past-the-end tiles read as zeros (buffer range check)
+    if constexpr (C::STAMP) tp1 = cycle_stamp();
     if (my_tiles > 0) {
-        w.qk(smem, kbase, sA0, sA1);
+        w.qk_all(smem, kbase, sA0, sA1);
         if (needs_mask(0)) w.mask(sA0, sA1, 0, q_row0, S, lane);
-        w.update_max(w.row_max(sA0, sA1), c);
+        w.first_max(w.row_max(sA0, sA1), c);   // m = row max of tile 0 (the reference of the optimistic pass)
     }
+    st.write_all(smem + SLOT);
+    __syncthreads();
+    if constexpr (C::STAMP) { tp2 = cycle_stamp(); acc[8] += tp1 - tp0; acc[9] += tp2 - tp1; }
 
-    // ring slot byte offsets of tiles t, t+1, t+2
-    int so_cur = 0, so_nxt = SLOT, so_wr = 2 * SLOT;
-
+    int so_cur = 0, so_nxt = SLOT, so_wr = 2 * SLOT;   // ring slot byte offsets of tiles t, t+1, t+2
     auto step = [&](int t, f32x16& cur0, f32x16& cur1, f32x16& nxt0, f32x16& nxt1) {
-        const bool more2 = t + 2 < n_tiles;
-        if (more2) st.load(Kh, Vh, kSb, vSb, (t + 2) * KVBLK, S, wave, lane);
+        unsigned long long t0 = 0, t4 = 0, t6 = 0;
+        if constexpr (C::STAMP) t0 = cycle_stamp();
         if (t < my_tiles) {
             const bool has_next = t + 1 < my_tiles;
-            w.full_step(smem + so_nxt, smem + so_cur + TILE, kbase, vbase, c, cur0, cur1, nxt0, nxt1, has_next,
-                        has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
+            w.template tile_step<TRACK>(st, t + 2, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur0,
+                                        cur1, nxt0, nxt1, has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S,
+                                        lane);
+        } else {
+            // wave already past its causal diagonal: it still stages its share of the tile
+            st.load_all(t + 2);
+            st.write_all(smem + so_wr);
         }
-        if (more2) st.write(smem + so_wr, smem + so_wr + TILE, wave, lane);
+        if constexpr (C::STAMP) t4 = cycle_stamp();
         __syncthreads();
+        if constexpr (C::STAMP) {
+            t6 = cycle_stamp();
+            acc[1] += w.t_mid - t0; acc[2] += w.t_end - w.t_mid; acc[3] += t4 - w.t_end; acc[5] += t6 - t4; acc[6] += 1;
+        }
         const int tmp = so_cur;
         so_cur = so_nxt;
         so_nxt = so_wr;
         so_wr = tmp;
     };
-
     for (int t = 0; t < n_tiles; t += 2) {
         step(t, sA0, sA1, sB0, sB1);
         if (t + 1 < n_tiles) step(t + 1, sB0, sB1, sA0, sA1);
     }
+    if constexpr (TRACK) return false;
+    else {
+        unsigned long long tc0 = 0;
+        if constexpr (C::STAMP) tc0 = cycle_stamp();
+        const bool bad = __syncthreads_or(my_tiles > 0 && w.not_finite()) != 0;
+        if constexpr (C::STAMP) acc[10] += cycle_stamp() - tc0;
+        return bad;
+    }
+}
 
-    if (wave_live) w.template store_o<OutT>(Oh, oSb, q_row0, S, lane);
+template <class C>
+__global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const Params p) {
+    constexpr int D = C::D, ESZ = C::ESZ;
+    constexpr bool CAUSAL = C::CAUSAL;
+    using OutT = typename C::OutT;
+    constexpr int KVBLK = 64, QBLK = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    lds_ptr smem = (lds_ptr)smem_raw;
+
+    int g, qb;
+    if (!unit_of_block(p, CAUSAL, g, qb)) return;
+    unsigned long long t_kernel0 = 0;
+    if constexpr (C::STAMP) t_kernel0 = cycle_stamp();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = g / p.H, h = g - b * p.H;
+    const int S = p.S;
+
+    const char* Qh = (const char*)p.Q + (b * p.qB + h * p.qH) * ESZ;
+    const char* Kh = (const char*)p.K + (b * p.kB + h * p.kH) * ESZ;
+    const char* Vh = (const char*)p.V + (b * p.vB + h * p.vH) * ESZ;
+    char* Oh = (char*)p.O + (b * p.oB + h * p.oH) * (int64_t)sizeof(OutT);
+    const int64_t qSb = p.qS * ESZ, kSb = p.kS * ESZ, vSb = p.vS * ESZ, oSb = p.oS * (int64_t)sizeof(OutT);
+
+    const int q_row0 = qb * QBLK + wave * 32;       // first query row of this wave
+    const int q_end = min(S, (qb + 1) * QBLK);      // one past the last query row of the block
+    const int n_tiles = CAUSAL ? (q_end + KVBLK - 1) / KVBLK : (S + KVBLK - 1) / KVBLK;
+    // tiles this wave computes: all (non-causal) or up to its own diagonal (causal)
+    const bool wave_live = q_row0 < S;
+    const int my_tiles = !wave_live ? 0 : (CAUSAL ? min(n_tiles, (q_row0 + 31) / KVBLK + 1) : n_tiles);
+
+    WaveCompute<C> w;
+    BufStage<D, ESZ> st;
+    st.init(Kh, Vh, kSb, vSb, S, wave, lane);
+    st.load_all(0);                                 // tile 0 and Q travel together (one HBM round trip)
+    w.load_q(Qh, qSb, q_row0, S, lane);
+    w.pin_q();
+    unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (C::STAMP) acc[7] = cycle_stamp() - t_kernel0;
+
+    if constexpr (C::OPTIMISTIC) {
+        if (attention_pass<C, false>(p, w, st, smem, n_tiles, my_tiles, q_row0, lane, acc, true))
+            attention_pass<C, true>(p, w, st, smem, n_tiles, my_tiles, q_row0, lane, acc, false);
+    } else {
+        attention_pass<C, true>(p, w, st, smem, n_tiles, my_tiles, q_row0, lane, acc, true);
+    }
+
+    unsigned long long t_ep0 = 0;
+    if constexpr (C::STAMP) t_ep0 = cycle_stamp();
+    if constexpr (sizeof(OutT) == 2) {
+        // every pass ends behind a workgroup barrier, so no wave still reads the K/V ring: reuse it
+        static_assert(8 * 32 * D * 2 <= C::LDS_BYTES, "epilogue regions must fit the ring");
+        if (wave_live) w.template store_o_lds<OutT>(smem + wave * (32 * D * 2), Oh, oSb, q_row0, S, lane);
+    } else {
+        if (wave_live) w.template store_o<OutT>(Oh, oSb, q_row0, S, lane);
+    }
+    if constexpr (C::STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store tail
+        const unsigned long long t_end = cycle_stamp();
+        acc[0] = t_end - t_kernel0;       // whole workgroup lifetime of this wave
+        acc[4] = t_end - t_ep0;           // epilogue: normalise + store O
+        if (lane == 0 && p.dbg) {
+#pragma unroll
+            for (int k = 0; k < 11; ++k) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + k] = acc[k];
+            p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 11] = 1;
+        }
+    }
 }
 
 }  // namespace fa

@@ -1,17 +1,21 @@
-// loaders.hip.h -- HBM -> registers -> LDS staging of K/V tiles, Q fragment loads, O epilogue.
+// loaders.hip.h -- HBM -> registers -> LDS staging of K/V tiles and the LDS images they land in.
 //
 // Counterpart of the reference's kernels/loaders.cuh: the LDS carve-up (:23-52), asyncBufferLoad
 // (:55-83), asyncWriteO (:85-112) and the two loader warps (:114-203).  Re-designed for CDNA4:
-//   * no dedicated loader warps and no cuda::pipeline: every wave stages 1/8 of each tile with
-//     issue-early / write-late register staging (global_load_dwordx4 before the tile's compute,
-//     ds_write_b128 after it), so HBM/L2 latency hides under the MFMA phases;
+//   * no dedicated loader warps and no cuda::pipeline: every wave stages 1/8 of each tile through
+//     registers, the loads issued inside the MFMA slots of the tile two iterations earlier and the
+//     ds_write_b128 inside later slots (computers.hip.h), so HBM/L2 latency hides under compute;
+//   * tiles are fetched with BUFFER loads: per-head descriptor in SGPRs, a per-lane byte offset that
+//     never changes, the tile offset one scalar-operand add -- no per-tile address arithmetic, and rows
+//     past the end of the sequence read as 0 through the hardware range check (no clamping);
 //   * each wave-instruction fetches 8 rows x 128 contiguous bytes (full cache lines) -- the
 //     reference's lane-contiguous fragments (loaders.cuh:57) are 32 rows x frag*4 B per request;
 //   * Q is never staged in LDS: each lane loads the MFMA B-fragments of its own query row once;
-//   * the K image is chunk-major  [d/8][key][8 x bf16]  so the 32 lanes of a half-wave read 512
-//     contiguous bytes per ds_read_b128 (conflict-free without an XOR swizzle, immediates only);
-//   * the V image is [key/8][d/32][key%8][d%32] so that ds_read_b64_tr_b16 (hardware transpose)
-//     feeds V^T straight into the PV MFMA: each half-wave reads 256 contiguous bytes.
+//   * the K image is chunk-major  [row bytes/16][64 keys][16 B]  so the 32 lanes of a half-wave read
+//     512 contiguous bytes per ds_read_b128 (conflict-free without an XOR swizzle, immediates only);
+//   * the V image is bf16 [key/8][d/32][key%8][d%32] so that ds_read_b64_tr_b16 (hardware transpose)
+//     feeds V^T straight into the PV MFMA: each half-wave reads 256 contiguous bytes.  fp8 inputs are
+//     widened to bf16 (exactly) on their way into this image.
 #pragma once
 
 #include "utils.hip.h"
@@ -50,69 +54,90 @@ __device__ __forceinline__ bool unit_of_block(const Params& p, bool causal, int&
     return true;
 }
 
-// ------------------------------------------------------------------------------------------------
-// K/V tile staging for the bf16 MFMA kernel: KVBLK = 64 keys, 512 threads.
-// ------------------------------------------------------------------------------------------------
-template <int D>
-struct KVStage {
+// Geometry of one 64-key tile.  ESZ = bytes per input element (2: bf16, 1: fp8 e4m3fn).
+template <int D, int ESZ>
+struct TileGeom {
     static constexpr int KVBLK = 64;
-    static constexpr int ROW_BYTES = D * 2;
-    static constexpr int TILE_BYTES = KVBLK * ROW_BYTES;       // 16 KiB (D=128) / 8 KiB (D=64)
-    static constexpr int CPT = TILE_BYTES / 16 / 512;          // 16-B chunks per thread: 2 / 1
     static constexpr int DB = D / 32;
+    static constexpr int ROWB = D * ESZ;                 // bytes of one K or V row in global memory
+    static constexpr int K_TILE = KVBLK * ROWB;          // K image keeps the input element type
+    static constexpr int V_TILE = KVBLK * D * 2;         // V image is always bf16
+    static constexpr int SLOT = K_TILE + V_TILE;         // ring slot = [K image | V image]
+    static constexpr int LOADS = ROWB / 128;             // 16-byte loads per thread per tensor per tile (512 threads)
+    static_assert(ROWB == 128 || ROWB == 256, "tile rows are one or two 128-byte lines");
 
-    u32x4 k[CPT];
-    u32x4 v[CPT];
-
-    // lane -> (key, chunk) of wave-instruction i.  One instruction = 8 keys x 128 B.
-    __device__ static int k_key(int wave, int lane) { return 8 * wave + (lane & 7); }
-    __device__ static int k_chunk(int i, int lane) { return 8 * i + (lane >> 3); }
-    __device__ static int v_key(int wave, int lane) { return 8 * wave + 2 * ((lane >> 3) & 3) + ((lane >> 2) & 1); }
-    __device__ static int v_chunk(int i, int lane) { return 8 * i + 4 * (lane >> 5) + (lane & 3); }
-
-    // LDS byte offsets inside one K / V tile image.
+    // LDS byte offsets inside the images.  K: 16-byte chunk c of key k.  V: bf16 chunk c (8 elements) of key k.
     __host__ __device__ static constexpr int k_lds_off(int key, int chunk) { return chunk * (KVBLK * 16) + key * 16; }
     __host__ __device__ static constexpr int v_lds_off(int key, int chunk) {
         return (key >> 3) * (DB * 512) + (chunk >> 2) * 512 + (key & 7) * 64 + (chunk & 3) * 16;
     }
-
-    // Issue the global loads of the tile starting at key row kv0 (rows clamped to S-1: pad,
-    // don't mask -- the padded keys are masked to -inf in the softmax).
-    __device__ __forceinline__ void load(const char* Kh, const char* Vh, int64_t kS_bytes,
-                                         int64_t vS_bytes, int kv0, int S, int wave, int lane) {
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            int kr = kv0 + k_key(wave, lane);
-            kr = kr < S ? kr : S - 1;
-            k[i] = *reinterpret_cast<const u32x4*>(Kh + kr * kS_bytes + k_chunk(i, lane) * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            int vr = kv0 + v_key(wave, lane);
-            vr = vr < S ? vr : S - 1;
-            v[i] = *reinterpret_cast<const u32x4*>(Vh + vr * vS_bytes + v_chunk(i, lane) * 16);
-        }
-    }
-
-    // Write the staged registers into the LDS images (ds_write_b128, 128 contiguous bytes per
-    // 8-lane group -> conflict-free).
-    __device__ __forceinline__ void write(lds_ptr kimg, lds_ptr vimg, int wave, int lane) const {
-#pragma unroll
-        for (int i = 0; i < CPT; ++i)
-            lds_write_b128(kimg, k_lds_off(k_key(wave, lane), k_chunk(i, lane)), k[i]);
-#pragma unroll
-        for (int i = 0; i < CPT; ++i)
-            lds_write_b128(vimg, v_lds_off(v_key(wave, lane), v_chunk(i, lane)), v[i]);
-    }
 };
 
 // Per-lane LDS read bases (everything else is an immediate offset).
-//   K A-fragment of k-step ks, key tile kt:  k_read_base + ks*2048 + kt*512
+//   K A-fragment: 16-byte chunk (2*s + h) of key 32*kt + (lane&31):  k_read_base + s*2048 + kt*512
 //   V^T A-fragment of d-block db, 16-key step s4, half jj: v_read_base + (2*s4+jj)*DB*512 + db*512
 __device__ __forceinline__ int k_read_base(int lane) { return (lane >> 5) * 1024 + (lane & 31) * 16; }
 __device__ __forceinline__ int v_read_base(int lane) {
     const int h = lane >> 5, q = (lane & 15) >> 2, p = lane & 3, g = (lane >> 4) & 1;
     return 256 * h + 64 * q + 32 * g + 8 * p;
 }
+
+// K/V tile staging.  One wave-instruction = 8 keys x 128 bytes; wave w owns keys 8w..8w+7 of every tile.
+//   K lanes: key 8w + (l&7),                    16-byte chunk (l>>3)          [+8 for the second 128-byte half]
+//   V lanes: key 8w + 2*((l>>3)&3) + ((l>>2)&1), 16-byte chunk 4*(l>>5)+(l&3) [+8 ...]
+// chosen so that each 8-lane ds_write_b128 group writes 128 contiguous LDS bytes in the respective image.
+template <int D, int ESZ>
+struct BufStage {
+    using G = TileGeom<D, ESZ>;
+    static constexpr int LOADS = G::LOADS;                       // per tensor
+    static constexpr int NL = 2 * LOADS;                         // loads per thread per tile
+    static constexpr int VW = ESZ == 1 ? 2 : 1;                  // ds_write_b128 per V load (fp8 widens to bf16)
+    static constexpr int NW = LOADS + LOADS * VW;                // LDS writes per thread per tile
+    __amdgpu_buffer_rsrc_t krsrc, vrsrc;
+    int koff, voff;        // per-lane byte offset of load 0 inside a tile (constant)
+    int klds, vlds;        // per-lane LDS byte offset of write 0 inside the K / V image
+    int ktile, vtile;      // bytes per 64-key tile step (scalar)
+    u32x4 r[NL];           // staged data: [0,LOADS) = K, [LOADS,NL) = V
+
+    __device__ __forceinline__ void init(const char* Kh, const char* Vh, int64_t kS_bytes, int64_t vS_bytes, int S,
+                                         int wave, int lane) {
+        // descriptor inputs are blockIdx / kernarg derived -> wave-uniform; num_records = the head's extent
+        krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (int)(S * kS_bytes), 0x00020000);
+        vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (int)(S * vS_bytes), 0x00020000);
+        ktile = (int)(64 * kS_bytes);
+        vtile = (int)(64 * vS_bytes);
+        const int kk = 8 * wave + (lane & 7), kc = lane >> 3;
+        const int vk = 8 * wave + 2 * ((lane >> 3) & 3) + ((lane >> 2) & 1), vc = 4 * (lane >> 5) + (lane & 3);
+        koff = kk * (int)kS_bytes + kc * 16;
+        voff = vk * (int)vS_bytes + vc * 16;
+        klds = G::k_lds_off(kk, kc);
+        vlds = G::v_lds_off(vk, ESZ == 1 ? 2 * vc : vc);   // fp8: 16 input bytes = bf16 chunks 2c, 2c+1
+    }
+    // load #N of tile t (N < LOADS: K half N, else V half N-LOADS).  The tile offset goes into the VGPR
+    // offset (one v_add with a scalar operand) so the hardware range check certainly covers it.
+    template <int N>
+    __device__ __forceinline__ void load(int t) {
+        if constexpr (N < LOADS)
+            r[N] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krsrc, koff + t * ktile + N * 128, 0, 0));
+        else
+            r[N] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, voff + t * vtile + (N - LOADS) * 128, 0, 0));
+    }
+    // LDS write #N (N < LOADS: K half N; then the V writes).  +8 K chunks = +8 KiB; +8 bf16 V chunks = +1 KiB.
+    template <int N>
+    __device__ __forceinline__ void write(lds_ptr slot_base) const {
+        if constexpr (N < LOADS) {
+            lds_write_b128(slot_base, klds + N * 8192, r[N]);
+        } else if constexpr (ESZ == 2) {
+            lds_write_b128(slot_base + G::K_TILE, vlds + (N - LOADS) * 1024, r[N]);
+        } else {
+            // fp8 V: 16 e4m3fn bytes -> 16 bf16 (exact), written as two adjacent 16-byte chunks
+            constexpr int W = N - LOADS;   // 0: low 8 bytes, 1: high 8 bytes of the single V load
+            const u32x4 src = r[LOADS];
+            lds_write_b128(slot_base + G::K_TILE, vlds + W * 16, fp8x8_to_bf16x8(src[2 * W], src[2 * W + 1]));
+        }
+    }
+    template <int N = 0> __device__ __forceinline__ void load_all(int t) { if constexpr (N < NL) { load<N>(t); load_all<N + 1>(t); } }
+    template <int N = 0> __device__ __forceinline__ void write_all(lds_ptr s) const { if constexpr (N < NW) { write<N>(s); write_all<N + 1>(s); } }
+};
 
 }  // namespace fa

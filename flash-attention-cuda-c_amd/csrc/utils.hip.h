@@ -37,6 +37,11 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
 __device__ __forceinline__ f32x16 mfma_32x32x16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
+// fp8 e4m3fn (OCP on gfx950) operands: 8 one-byte elements per lane, same (row, k = 8h+j) lane map,
+// same rate as the bf16 instruction (the 2x rate needs the block-scaled f8f6f4 form).
+__device__ __forceinline__ f32x16 mfma_32x32x16_fp8(uint64_t a, uint64_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8((long)a, (long)b, c, 0, 0, 0);
+}
 
 // Row of the 32x32 accumulator tile held in register `reg` of lane half `h`.
 __host__ __device__ constexpr int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
@@ -95,6 +100,23 @@ __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
     v[0] = (_Float16)lo;
     v[1] = (_Float16)hi;
     return __builtin_bit_cast(uint32_t, v);
+}
+
+// 8 fp8 e4m3fn bytes (two dwords) -> 8 bf16, exactly (e4m3fn has 3 mantissa bits): 4 v_cvt_pk_f32_fp8 +
+// 4 v_cvt_pk_bf16_f32.
+__device__ __forceinline__ u32x4 fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    return u32x4{pack_bf16(a[0], a[1]), pack_bf16(b[0], b[1]), pack_bf16(c[0], c[1]), pack_bf16(d[0], d[1])};
+}
+
+// s_memtime stamp for diagnostic builds: one asm statement with its own wait, fenced (guide: In-kernel stamps).
+__device__ __forceinline__ unsigned long long cycle_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32

@@ -19,11 +19,13 @@
 
 inline int calculateSizeBlockQ(int d_head, int dtype) {
     if (dtype == FA_DTYPE_BF16 && (d_head == 64 || d_head == 128)) return 256;
+    if (dtype == FA_DTYPE_FP8_E4M3 && d_head == 128) return 256;
     return 32;
 }
 
 inline int calculateSizeBlockKV(int d_head, int dtype) {
     if (dtype == FA_DTYPE_BF16 && (d_head == 64 || d_head == 128)) return 64;
+    if (dtype == FA_DTYPE_FP8_E4M3 && d_head == 128) return 64;
     return 32;
 }
 

@@ -16,10 +16,6 @@
 #include <vector>
 
 #include "../flash-attention-cuda-c_amd/csrc/kernel_bf16.hip.h"
-#include "../flash-attention-cuda-c_amd/csrc/kernel_bf16_slots.hip.h"
-#include "../flash-attention-cuda-c_amd/csrc/kernel_bf16_v4.hip.h"
-#include "../flash-attention-cuda-c_amd/csrc/kernel_bf16_v5.hip.h"
-#include "../flash-attention-cuda-c_amd/csrc/kernel_bf16_v1.hip.h"
 #include "../oracle/cpu_attention.h"
 
 #define HIP_CHECK(x)                                                                          \
@@ -55,59 +51,23 @@ struct Variant {
 };
 
 template <class K>
-static void launch_pipelined(const Params& p, int grid) {
-    constexpr int lds = 3 * 2 * KVStage<K::D>::TILE_BYTES;
+static void launch_cfg(const Params& p, int grid) {
     static bool once = [] {
-        HIP_CHECK(hipFuncSetAttribute((const void*)fwd_bf16_pipelined_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)fwd_mfma_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((fwd_bf16_pipelined_kernel<K>), dim3(grid), dim3(512), lds, nullptr, p);
-}
-template <class K>
-static void launch_slots(const Params& p, int grid) {
-    constexpr int lds = 3 * 2 * KVStage<K::D>::TILE_BYTES;
-    static bool once = [] {
-        HIP_CHECK(hipFuncSetAttribute((const void*)fwd_bf16_slots_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        return true;
-    }();
-    (void)once;
-    hipLaunchKernelGGL((fwd_bf16_slots_kernel<K>), dim3(grid), dim3(512), lds, nullptr, p);
-}
-template <class K>
-static void launch_v4(const Params& p, int grid) {
-    constexpr int lds = 3 * 2 * KVStage<K::D>::TILE_BYTES;
-    static bool once = [] {
-        HIP_CHECK(hipFuncSetAttribute((const void*)fwd_bf16_v4_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        return true;
-    }();
-    (void)once;
-    hipLaunchKernelGGL((fwd_bf16_v4_kernel<K>), dim3(grid), dim3(512), lds, nullptr, p);
-}
-template <class K>
-static void launch_v5(const Params& p0, int) {
-    Params p = p0;
-    constexpr int QBLK = 32 * K::NW;
-    p.nQ = (p.S + QBLK - 1) / QBLK;
-    p.units = p.B * p.H * p.nQ;
-    p.cpx = (p.units + 7) / 8;
-    constexpr int lds = 4 * KVStage<K::D>::TILE_BYTES;
-    hipLaunchKernelGGL((fwd_bf16_v5_kernel<K>), dim3(8 * p.cpx), dim3(64 * K::NW), lds, nullptr, p);
-}
-template <int D, bool CAUSAL>
-static void launch_v1(const Params& p, int grid) {
-    constexpr int lds = 2 * 2 * KVStage<D>::TILE_BYTES;
-    hipLaunchKernelGGL((fwd_bf16_kernel<D, CAUSAL, __bf16>), dim3(grid), dim3(512), lds, nullptr, p);
+    hipLaunchKernelGGL((fwd_mfma_kernel<K>), dim3(grid), dim3(512), K::LDS_BYTES, nullptr, p);
 }
 
+// KernelCfg<D, CAUSAL, OutT, ESZ, STAMP, OPTIMISTIC, NPRE, VPRE, THR>
 template <int D, bool CAUSAL>
 static std::vector<Variant> make_variants() {
     std::vector<Variant> v;
-    v.push_back({"v1 2-slot unpipelined", launch_v1<D, CAUSAL>});
-    v.push_back({"v4 tracked only", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 4, 2, false, 0, false>>});
-    v.push_back({"v4 optimistic+fallback", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 4, 2, false, 0, true>>});
-    v.push_back({"v4 optimistic npre6 vpre3", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 6, 3, false, 0, true>>});
-    v.push_back({"v4 optimistic STAMP", launch_v4<V4Cfg<D, CAUSAL, __bf16, 8, 4, 2, true, 0, true>>});
+    v.push_back({"production (optimistic, npre4 vpre2)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2>>});
+    v.push_back({"tracked only", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, false, 4, 2>>});
+    v.push_back({"optimistic npre6 vpre3", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 6, 3>>});
+    v.push_back({"production STAMP", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, true, true, 4, 2>>});
     return v;
 }
 
@@ -155,8 +115,8 @@ int main(int argc, char** argv) {
     p.scale_log2 = p.scale * 1.4426950408889634f;
     const int grid = 8 * p.cpx;
     unsigned long long* ddbg;
-    HIP_CHECK(hipMalloc(&ddbg, (size_t)grid * 64 * 8));
-    HIP_CHECK(hipMemset(ddbg, 0, (size_t)grid * 64 * 8));
+    HIP_CHECK(hipMalloc(&ddbg, (size_t)grid * 128 * 8));
+    HIP_CHECK(hipMemset(ddbg, 0, (size_t)grid * 128 * 8));
     p.dbg = ddbg;
 
     std::vector<Variant> vars;
@@ -223,20 +183,29 @@ int main(int argc, char** argv) {
             HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
             ms[vi].push_back(t / reps);
         }
-    {   // segment stamps of the STAMP variant (if it ran): average cycles per tile per wave
-        std::vector<unsigned long long> h((size_t)grid * 64);
+    {   // segment stamps of the STAMP variant (if it ran)
+        std::vector<unsigned long long> h((size_t)grid * 128);
         HIP_CHECK(hipMemcpy(h.data(), ddbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double seg[7] = {0, 0, 0, 0, 0, 0, 0};
+        double seg[12] = {0};
         for (size_t i = 0; i < (size_t)grid * 8; ++i)
-            for (int k = 0; k < 7; ++k) seg[k] += (double)h[i * 8 + k];
-        if (seg[6] > 0) {
-            const char* nm[6] = {"issue stage loads (v3 only)", "phase A (QK^T + exp)", "phase B (PV + max)", "max update/rescale",
-                                 "stage write (vmcnt+ds_write)", "barrier"};
-            double tot = 0;
-            for (int k = 0; k < 6; ++k) tot += seg[k] / seg[6];
-            printf("  STAMP build: cycles per tile per wave (avg over %.0f wave-tiles), each stamp costs ~40-60:\n", seg[6]);
-            for (int k = 0; k < 6; ++k) printf("      %-30s %8.1f  (%4.1f%%)\n", nm[k], seg[k] / seg[6], 100.0 * seg[k] / seg[6] / tot);
-            printf("      %-30s %8.1f\n", "total", tot);
+            for (int k = 0; k < 12; ++k) seg[k] += (double)h[i * 16 + k];
+        if (seg[6] > 0 && !causal) {
+            const double nt = seg[6], nw = seg[11] > 0 ? seg[11] : 1;
+            printf("  STAMP build (each stamp costs ~40-60 cycles):\n");
+            printf("    per tile per wave (%.0f wave-tiles): phase A %.1f | phase B %.1f | end-of-tile %.1f | barrier %.1f | sum %.1f\n", nt,
+                   seg[1] / nt, seg[2] / nt, seg[3] / nt, seg[5] / nt, (seg[1] + seg[2] + seg[3] + seg[5]) / nt);
+            for (int wv = 0; wv < 8; ++wv) {   // per wave index: does the older half (waves 0-3) wait at the barrier?
+                double a = 0, b = 0, bar = 0, n = 0;
+                for (size_t g = 0; g < (size_t)grid; ++g) {
+                    const unsigned long long* r = &h[(g * 8 + wv) * 16];
+                    a += (double)r[1]; b += (double)r[2]; bar += (double)r[5]; n += (double)r[6];
+                }
+                if (n > 0) printf("      wave %d: phase A %.0f  phase B %.0f  barrier wait %.0f\n", wv, a / n, b / n, bar / n);
+            }
+            const double loop = (seg[1] + seg[2] + seg[3] + seg[5]) / nw, tot = seg[0] / nw;
+            printf("    per workgroup-wave (%.0f waves): lifetime %.0f = Q load+pin %.0f | stage tiles 0,1 + barrier %.0f | QK(0)+max %.0f | tile loop %.0f (%.1f%%) | finite check %.0f | epilogue %.0f | unaccounted %.0f\n",
+                   nw, tot, seg[7] / nw, seg[8] / nw, seg[9] / nw, loop, 100 * loop / tot, seg[10] / nw, seg[4] / nw,
+                   tot - loop - (seg[7] + seg[8] + seg[9] + seg[10] + seg[4]) / nw);
         }
     }
     const double flops = (causal ? 2.0 : 4.0) * BH * (double)S * S * d;

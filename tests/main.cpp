@@ -6,7 +6,7 @@
 // tolerance, times the kernel with hipEvents, and exits non-zero on failure.
 //
 // usage: fa_test [--quick] [--perf] [--case B H S d causal dtype o_dtype]...
-//   dtype/o_dtype: 0 = f32, 1 = bf16, 3 = f16 (output only)
+//   dtype/o_dtype: 0 = f32, 1 = bf16, 2 = fp8 e4m3fn (input only), 3 = f16 (output only)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -76,7 +76,7 @@ static Result run_case(const Case& c, bool perf, int iters) {
             for (int j = 0; j < c.d; ++j)
                 hk[((int64_t)g * c.S + (c.S / 2 + 5) % c.S) * c.d + j] = 6.0f * hq[((int64_t)g * c.S + 3 % c.S) * c.d + j];
     }
-    const int esz = c.dtype == FA_DTYPE_F32 ? 4 : 2;
+    const int esz = c.dtype == FA_DTYPE_F32 ? 4 : (c.dtype == FA_DTYPE_FP8_E4M3 ? 1 : 2);
     const int osz = c.o_dtype == FA_DTYPE_F32 ? 4 : 2;
     std::vector<uint16_t> bq, bk, bv;
     if (c.dtype == FA_DTYPE_BF16) {
@@ -87,12 +87,21 @@ static Result run_case(const Case& c, bool perf, int iters) {
             bv[i] = oracle_f32_to_bf16(hv[i]); hv[i] = oracle_bf16_to_f32(bv[i]);
         }
     }
+    std::vector<uint8_t> eq, ek, ev;
+    if (c.dtype == FA_DTYPE_FP8_E4M3) {   // OCP e4m3fn inputs: the oracle sees the rounded values
+        eq.resize(n); ek.resize(n); ev.resize(n);
+        for (int64_t i = 0; i < n; ++i) {
+            eq[i] = oracle_f32_to_e4m3fn(hq[i]); hq[i] = oracle_e4m3fn_to_f32(eq[i]);
+            ek[i] = oracle_f32_to_e4m3fn(hk[i]); hk[i] = oracle_e4m3fn_to_f32(ek[i]);
+            ev[i] = oracle_f32_to_e4m3fn(hv[i]); hv[i] = oracle_e4m3fn_to_f32(ev[i]);
+        }
+    }
     void *dq, *dk, *dv, *dout;
     HIP_CHECK(hipMalloc(&dq, n * esz)); HIP_CHECK(hipMalloc(&dk, n * esz));
     HIP_CHECK(hipMalloc(&dv, n * esz)); HIP_CHECK(hipMalloc(&dout, n * osz));
-    const void *sq = esz == 4 ? (void*)hq.data() : (void*)bq.data();
-    const void *sk = esz == 4 ? (void*)hk.data() : (void*)bk.data();
-    const void *sv = esz == 4 ? (void*)hv.data() : (void*)bv.data();
+    const void *sq = esz == 4 ? (void*)hq.data() : esz == 2 ? (void*)bq.data() : (void*)eq.data();
+    const void *sk = esz == 4 ? (void*)hk.data() : esz == 2 ? (void*)bk.data() : (void*)ek.data();
+    const void *sv = esz == 4 ? (void*)hv.data() : esz == 2 ? (void*)bv.data() : (void*)ev.data();
     HIP_CHECK(hipMemcpy(dq, sq, n * esz, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dk, sk, n * esz, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dv, sv, n * esz, hipMemcpyHostToDevice));
@@ -208,10 +217,17 @@ int main(int argc, char** argv) {
         cases.push_back({1, 2, 1024, 128, 0, 1, 0, 2});   // spike: forces the rescale branch
         cases.push_back({1, 2, 1024, 128, 1, 1, 0, 2});
         cases.push_back({1, 2, 200, 80, 1, 1, 0, 0});     // bf16 on the generic path (d = 80)
+        // fp8 e4m3fn inputs (QK^T on the fp8 MFMA, V widened to bf16 on the way into LDS)
+        cases.push_back({1, 1, 64, 128, 0, 2, 0, 0});
+        cases.push_back({1, 1, 64, 128, 0, 2, 0, 1});
+        cases.push_back({2, 2, 512, 128, 1, 2, 0, 0});
+        cases.push_back({1, 3, 1000, 128, 0, 2, 1, 0});
+        cases.push_back({1, 2, 1024, 128, 1, 2, 0, 2});
         if (!quick) {
             cases.push_back({4, 8, 2048, 64, 0, 1, 0, 0});    // BASELINE cfg1
             cases.push_back({8, 16, 4096, 128, 1, 1, 0, 0});  // BASELINE cfg2 (sampled heads)
             cases.push_back({8, 16, 4096, 128, 0, 1, 0, 0});
+            cases.push_back({1, 16, 16384, 128, 0, 2, 1, 0}); // BASELINE cfg3: fp8 e4m3, S=16384, d=128 (B=1, H=16 chosen)
         }
     }
     int fails = 0;

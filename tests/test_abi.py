@@ -44,6 +44,7 @@ def test_argument_validation_happens_before_any_launch():
     assert call(K=p + 4) == -2                                       # FA_ERR_MISALIGNED
     assert call(S=0) == -3 and call(B=-1) == -3                      # FA_ERR_BAD_SHAPE
     assert call(d=512) == -4 and call(d=3) == -4                     # FA_ERR_UNSUPPORTED_DHEAD
+    assert call(dtype=2, d=64) == -4 and call(dtype=2, d=16) == -4   # fp8 e4m3fn: d = 128 only
     assert call(dtype=9) == -5 and call(o=2) == -5                   # FA_ERR_UNSUPPORTED_DTYPE
     assert call(scale=float("nan")) == -6 and call(scale=float("inf")) == -6
     for code in range(-7, 1):
@@ -71,6 +72,7 @@ def test_strided_validation():
     (4, 8, 2048, 64, False, fa.FA_DTYPE_BF16, 1, 256, 64),     # BASELINE cfg1
     (1, 1, 16, 16, False, fa.FA_DTYPE_F32, 0, 32, 32),         # tests/main.cu:107
     (1, 2, 200, 80, True, fa.FA_DTYPE_BF16, 0, 32, 32),        # bf16, d not in {64,128}
+    (1, 16, 16384, 128, False, fa.FA_DTYPE_FP8_E4M3, 2, 256, 64),  # BASELINE cfg3 (fp8 e4m3fn)
 ])
 def test_launch_plan(B, H, S, d, causal, dtype, kid, br, bc):
     p = fa.plan(B, H, S, d, causal, dtype, fa.FA_DTYPE_F32)
@@ -81,6 +83,8 @@ def test_launch_plan(B, H, S, d, causal, dtype, kid, br, bc):
     assert p["threads"] % 64 == 0 and p["lds_bytes"] <= 160 * 1024
     if kid == 1:
         assert p["lds_bytes"] == 3 * 2 * 64 * d * 2      # 3-slot ring of K+V tiles
+    if kid == 2:
+        assert p["lds_bytes"] == 3 * 64 * d * 3          # fp8 K image + bf16 V image
 
 
 def test_no_cpu_fallback_in_binding():

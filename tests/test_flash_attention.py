@@ -186,6 +186,41 @@ def test_optimistic_pass_falls_back_to_tracked_max(d, causal):
     check(run_gpu(Q, K2, V, causal), ref, 4e-3, 4e-3, rms=1e-3)
 
 
+FP8 = getattr(torch, "float8_e4m3fn", None)
+
+
+@pytest.mark.skipif(FP8 is None, reason="torch build without float8_e4m3fn")
+@pytest.mark.parametrize("B,H,S,causal", [(1, 1, 64, False), (2, 2, 512, True), (1, 3, 1000, False), (1, 2, 1024, True),
+                                          (1, 1, 1, True), (1, 2, 4096, False)])
+def test_fp8_e4m3_inputs_match_oracle(B, H, S, causal):
+    """BASELINE cfg3's dtype: OCP e4m3fn Q/K/V (d = 128).  QK^T runs on v_mfma_f32_32x32x16_fp8_fp8, V is
+    widened to bf16 exactly, so the only rounding inside the kernel is P -> bf16: same tolerance as bf16."""
+    d = 128
+    Q, K, V = (randn((B, H, S, d), s, torch.float32).to(FP8) for s in (60, 61, 62))
+    ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=causal)
+    np.testing.assert_array_equal(oracle.round_e4m3fn(Q.float().numpy()), Q.float().numpy())   # same e4m3fn grid
+    check(run_gpu(Q, K, V, causal), ref, 4e-3, 4e-3, rms=1e-3)
+    O = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal)     # default output: bf16
+    torch.cuda.synchronize()
+    assert O.dtype == torch.bfloat16
+    check(O.float().cpu().numpy(), ref, 8e-3, 8e-3)
+
+
+@pytest.mark.skipif(FP8 is None, reason="torch build without float8_e4m3fn")
+def test_fp8_golden_inputs(golden):
+    """F5e4m3: check.py on inputs rounded to float8_e4m3fn by torch (d = 64 there, so the 128-wide kernel
+    cannot take it directly): two heads are concatenated into one d = 128 head whose second half of Q is
+    zero -- scores and therefore the first 64 output columns are unchanged."""
+    Q, K, V = (torch.from_numpy(golden.load("F5e4m3", k)) for k in "QKV")        # (1,128,64)
+    z = torch.zeros_like(Q)
+    Q2, K2, V2 = torch.cat([Q, z], -1), torch.cat([K, K], -1), torch.cat([V, V], -1)
+    scale = 1.0 / 64 ** 0.5
+    O = fa.flash_attention(Q2.to(FP8).to(DEV)[:, None], K2.to(FP8).to(DEV)[:, None], V2.to(FP8).to(DEV)[:, None],
+                           scale=scale, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    check(O[0, 0, :, :64].cpu().numpy(), golden.load("F5e4m3", "out")[0], 4e-3, 4e-3, rms=1e-3)
+
+
 def test_heads_are_independent():
     """Reference defect D2 (every query attends to every batch/head) must not be reproduced:
     a head computed alone equals the same head computed inside a batch, bit for bit."""
