@@ -43,6 +43,18 @@ def flops_of(BH, S, d, causal):
     return (2.0 if causal else 4.0) * BH * float(S) * S * d
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch from the committed PMC run of this same command (separate FETCH_SIZE / WRITE_SIZE
+    passes, FETCH_SIZE doubled as the gfx950 guide prescribes) -- profiles/r01_hbm_traffic_<workload>.json;
+    None when no such measurement is committed for the workload."""
+    path = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            return int(json.load(f)["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(S, d, causal, budget_s=12.0):
     """Naive fp32 attention (the oracle, a port of tests/main.cu:74-91 / check.py:19-21) on the host
     cores, on a bounded sample: as many whole heads of the workload's (S, d) as fit ~budget_s."""
@@ -163,7 +175,8 @@ def main():
             "pct_of_bf16_mfma_peak": round(100.0 * value / (PEAK_BF16_TFLOPS * n_gpus), 2),
             "output_ok": ok_all,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         "traffic": measured_traffic(args.workload) if n_gpus == 1 else None,
                          "kernel": "fa::fwd_mfma_kernel", "kernel_ms": round(kernel_ms_max, 5),
                          "algorithmic_hbm_bytes": heads_local * S * d * (3 * Q.element_size() + O.element_size()),
                          "algorithmic_hbm_GBps": round(heads_local * S * d * (3 * Q.element_size() + O.element_size())
