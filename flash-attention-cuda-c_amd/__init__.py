@@ -27,7 +27,7 @@ LIB_PATH = os.path.join(_HERE, "libflash_attention.so")
 FA_DTYPE_F32, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3, FA_DTYPE_F16 = 0, 1, 2, 3
 
 # every symbol include/flash_attention.h declares
-EXPORTS = ("flash_attention", "flash_attention_strided", "flash_attention_plan",
+EXPORTS = ("flash_attention", "flash_attention_strided", "flash_attention_lse", "flash_attention_plan",
            "flash_attention_error_string", "flash_attention_version")
 
 
@@ -64,6 +64,8 @@ def lib() -> ctypes.CDLL:
         sp = ctypes.POINTER(FaStrides)
         L.flash_attention_strided.argtypes = [vp, vp, vp, vp, i, i, i, i, f, b, i, i, sp, sp, sp, sp, vp]
         L.flash_attention_strided.restype = i
+        L.flash_attention_lse.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, f, b, i, i, vp]
+        L.flash_attention_lse.restype = i
         L.flash_attention_plan.argtypes = [i, i, i, i, b, i, i, ctypes.POINTER(FaLaunchPlan)]
         L.flash_attention_plan.restype = i
         L.flash_attention_error_string.argtypes = [i]
@@ -121,13 +123,14 @@ def plan(batchSize, numHeads, seqLen, dHead, is_causal=False, dtype=FA_DTYPE_BF1
     return {k: getattr(p, k) for k, _ in FaLaunchPlan._fields_}
 
 
-def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None, stream=None):
+def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None, stream=None, return_lse=False):
     """O = softmax(scale * Q K^T [+ causal mask]) V on dense [B, H, S, d] device tensors.
 
     Argument order and meaning follow the reference kernel (Q, K, V, O, batchSize, numHeads,
     seqLen, scale, is_causal -- kernels/FlashAttention.cuh:59-63); batchSize/numHeads/seqLen/dHead
     are read from Q.shape, ``scale`` defaults to 1/sqrt(d) (tests/main.cu:27).  Asynchronous on
-    ``stream`` (default: torch's current stream).  Returns O.
+    ``stream`` (default: torch's current stream).  Returns O, or ``(O, LSE)`` with ``return_lse=True``
+    (LSE: fp32 [B, H, S], natural-log sum of exp(scale * scores) over the visible keys; dense tensors only).
     """
     import torch
     if not (Q.is_cuda and K.is_cuda and V.is_cuda):
@@ -144,8 +147,17 @@ def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None
     elif O.shape != Q.shape or not O.is_cuda:
         raise ValueError("O must be a device tensor shaped like Q")
     dense = all(t.is_contiguous() for t in (Q, K, V, O))
+    lse = None
+    if return_lse:
+        if not dense:
+            raise ValueError("return_lse needs dense [B, H, S, d] tensors")
+        lse = torch.empty((B, H, S), dtype=torch.float32, device=Q.device)
     with torch.cuda.device(Q.device):
-        if dense:
+        if lse is not None:
+            rc = lib().flash_attention_lse(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), lse.data_ptr(), B, H, S,
+                                           d, float(scale), bool(is_causal), _dtype_code(Q.dtype), _dtype_code(O.dtype),
+                                           _stream_ptr(stream))
+        elif dense:
             rc = lib().flash_attention(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, S, d,
                                        float(scale), bool(is_causal), _dtype_code(Q.dtype), _dtype_code(O.dtype),
                                        _stream_ptr(stream))
@@ -160,7 +172,7 @@ def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None
                                                _dtype_code(O.dtype), ctypes.byref(st[0]), ctypes.byref(st[1]),
                                                ctypes.byref(st[2]), ctypes.byref(st[3]), _stream_ptr(stream))
     _check(rc)
-    return O
+    return (O, lse) if return_lse else O
 
 
 def multi_head_attention(Q, K, V, num_heads, is_causal=False, return_attn=False, out_dtype=None):

@@ -21,10 +21,10 @@ namespace fa {
 // ------------------------------------------------------------------------------------------------
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-static int fill_params(Params& p, const void* Q, const void* K, const void* V, void* O, int B, int H,
+static int fill_params(Params& p, const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H,
                        int S, int d, float scale, const fa_strides* sQ, const fa_strides* sK,
                        const fa_strides* sV, const fa_strides* sO) {
-    p.Q = Q; p.K = K; p.V = V; p.O = O;
+    p.Q = Q; p.K = K; p.V = V; p.O = O; p.lse = lse;
     const int64_t dS = d, dH = (int64_t)S * d, dB = (int64_t)H * S * d;
     p.qB = sQ ? sQ->strideB : dB; p.qH = sQ ? sQ->strideH : dH; p.qS = sQ ? sQ->strideS : dS;
     p.kB = sK ? sK->strideB : dB; p.kH = sK ? sK->strideH : dH; p.kS = sK ? sK->strideS : dS;
@@ -129,11 +129,12 @@ static hipError_t launch_generic(const Params& p, const fa_launch_plan& plan, in
     return launch_generic_io<InT, _Float16>(p, plan, d, causal, st);
 }
 
-static int run(const void* Q, const void* K, const void* V, void* O, int B, int H, int S, int d,
+static int run(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int S, int d,
                float scale, bool causal, int dtype, int o_dtype, const fa_strides* sQ,
                const fa_strides* sK, const fa_strides* sV, const fa_strides* sO, void* stream) {
     int rc = validate(Q, K, V, O, B, H, S, d, scale, dtype, o_dtype);
     if (rc != FA_OK) return rc;
+    if (lse && !aligned16(lse)) return FA_ERR_MISALIGNED;
     const int esz = elem_size(dtype), osz = elem_size(o_dtype);
     if (!strides_ok(sQ, esz, d) || !strides_ok(sK, esz, d) || !strides_ok(sV, esz, d) || !strides_ok(sO, osz, d))
         return FA_ERR_BAD_STRIDE;
@@ -146,7 +147,7 @@ static int run(const void* Q, const void* K, const void* V, void* O, int B, int 
         if (((int64_t)S + 192) * ks * esz >= (1ll << 31) || ((int64_t)S + 192) * vs * esz >= (1ll << 31)) return FA_ERR_BAD_SHAPE;
     }
     Params p;
-    fill_params(p, Q, K, V, O, B, H, S, d, scale, sQ, sK, sV, sO);
+    fill_params(p, Q, K, V, O, lse, B, H, S, d, scale, sQ, sK, sV, sO);
     p.nQ = getNumCta(S, plan.q_block_rows);
     p.units = B * H * p.nQ;
     p.cpx = (p.units + 7) / 8;
@@ -173,7 +174,13 @@ extern "C" {
 int flash_attention(const void* Q, const void* K, const void* V, void* O, int batchSize, int numHeads,
                     int seqLen, int dHead, float scale, bool is_causal, int dtype, int o_dtype,
                     void* stream) {
-    return fa::run(Q, K, V, O, batchSize, numHeads, seqLen, dHead, scale, is_causal, dtype, o_dtype,
+    return fa::run(Q, K, V, O, nullptr, batchSize, numHeads, seqLen, dHead, scale, is_causal, dtype, o_dtype,
+                   nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int flash_attention_lse(const void* Q, const void* K, const void* V, void* O, float* LSE, int batchSize, int numHeads,
+                        int seqLen, int dHead, float scale, bool is_causal, int dtype, int o_dtype, void* stream) {
+    return fa::run(Q, K, V, O, LSE, batchSize, numHeads, seqLen, dHead, scale, is_causal, dtype, o_dtype,
                    nullptr, nullptr, nullptr, nullptr, stream);
 }
 
@@ -181,7 +188,7 @@ int flash_attention_strided(const void* Q, const void* K, const void* V, void* O
                             int numHeads, int seqLen, int dHead, float scale, bool is_causal, int dtype,
                             int o_dtype, const fa_strides* sQ, const fa_strides* sK,
                             const fa_strides* sV, const fa_strides* sO, void* stream) {
-    return fa::run(Q, K, V, O, batchSize, numHeads, seqLen, dHead, scale, is_causal, dtype, o_dtype, sQ,
+    return fa::run(Q, K, V, O, nullptr, batchSize, numHeads, seqLen, dHead, scale, is_causal, dtype, o_dtype, sQ,
                    sK, sV, sO, stream);
 }
 

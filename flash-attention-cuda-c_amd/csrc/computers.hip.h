@@ -303,9 +303,17 @@ struct WaveCompute {
     // ---- epilogues -----------------------------------------------------------------------------
     // Direct form: divide by the row sum and store O[q][d].  A lane holds d = 32db + 8g4 + 4h + (0..3).
     // Used for 4-byte outputs (the reference's float* O).
+    // ln sum_k exp(scale*s_k) = (m + log2 l) * ln 2   (m is the reference max in the scaled log2 domain)
+    __device__ __forceinline__ void store_lse(float* lse_head, float l_tot, int row0, int S, int lane) const {
+        const int qi = row0 + (lane & 31);
+        if (lse_head && lane < 32 && qi < S) lse_head[qi] = (m + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+    }
+
     template <typename OutT>
-    __device__ __forceinline__ void store_o(char* Oh, int64_t oS_bytes, int row0, int S, int lane) {
-        const float inv = 1.0f / sum_both_halves(l);
+    __device__ __forceinline__ void store_o(char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S, int lane) {
+        const float l_tot = sum_both_halves(l);
+        store_lse(lse_head, l_tot, row0, S, lane);
+        const float inv = 1.0f / l_tot;
         const int qi = row0 + (lane & 31);
         const int h = lane >> 5;
         if (qi >= S) return;
@@ -336,10 +344,13 @@ struct WaveCompute {
     // ds_write_b64 of 16 lanes (16 rows, same column) spread over all banks.  `region` = 32*D*2 bytes
     // private to this wave; the caller guarantees the K/V ring is dead.
     template <typename OutT>
-    __device__ __forceinline__ void store_o_lds(lds_ptr region, char* Oh, int64_t oS_bytes, int row0, int S, int lane) {
+    __device__ __forceinline__ void store_o_lds(lds_ptr region, char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S,
+                                                int lane) {
         static_assert(sizeof(OutT) == 2, "LDS epilogue is for bf16 / f16 outputs");
         constexpr int ROWB = D * 2, CHUNKS = ROWB / 16;
-        const float inv = 1.0f / sum_both_halves(l);
+        const float l_tot = sum_both_halves(l);
+        store_lse(lse_head, l_tot, row0, S, lane);
+        const float inv = 1.0f / l_tot;
         const int q = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int db = 0; db < DB; ++db)

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void fwd_generic_kernel(const Params p, const 
     }
 
     if (qi < S) {
+        if (p.lse && sub == 0) p.lse[(int64_t)g * S + qi] = m + logf(l);   // natural-log domain: m = max(scale*s)
         const float inv = 1.0f / l;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const Params p) {
     const char* Kh = (const char*)p.K + (b * p.kB + h * p.kH) * ESZ;
     const char* Vh = (const char*)p.V + (b * p.vB + h * p.vH) * ESZ;
     char* Oh = (char*)p.O + (b * p.oB + h * p.oH) * (int64_t)sizeof(OutT);
+    float* lse_head = p.lse ? p.lse + (int64_t)g * S : nullptr;
     const int64_t qSb = p.qS * ESZ, kSb = p.kS * ESZ, vSb = p.vS * ESZ, oSb = p.oS * (int64_t)sizeof(OutT);
 
     const int q_row0 = qb * QBLK + wave * 32;       // first query row of this wave
@@ -163,9 +164,9 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const Params p) {
     if constexpr (sizeof(OutT) == 2) {
         // every pass ends behind a workgroup barrier, so no wave still reads the K/V ring: reuse it
         static_assert(8 * 32 * D * 2 <= C::LDS_BYTES, "epilogue regions must fit the ring");
-        if (wave_live) w.template store_o_lds<OutT>(smem + wave * (32 * D * 2), Oh, oSb, q_row0, S, lane);
+        if (wave_live) w.template store_o_lds<OutT>(smem + wave * (32 * D * 2), Oh, lse_head, oSb, q_row0, S, lane);
     } else {
-        if (wave_live) w.template store_o<OutT>(Oh, oSb, q_row0, S, lane);
+        if (wave_live) w.template store_o<OutT>(Oh, lse_head, oSb, q_row0, S, lane);
     }
     if constexpr (C::STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store tail

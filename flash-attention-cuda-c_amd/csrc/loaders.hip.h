@@ -28,6 +28,7 @@ struct Params {
     const void* K;
     const void* V;
     void* O;
+    float* lse;       // optional [B,H,S] fp32 log-sum-exp (natural log) of every softmax row, or nullptr
     int64_t qB, qH, qS;
     int64_t kB, kH, kS;
     int64_t vB, vH, vS;

@@ -49,7 +49,7 @@ enum {
     FA_DTYPE_F32 = 0,      /* IEEE fp32 -- the reference's own type (const float*) */
     FA_DTYPE_BF16 = 1,     /* bfloat16, fp32 accumulation on MFMA */
     FA_DTYPE_FP8_E4M3 = 2, /* OCP e4m3fn (not fnuz); inputs only */
-    FA_DTYPE_F16 = 3       /* IEEE fp16; output only in this round */
+    FA_DTYPE_F16 = 3       /* IEEE fp16; output only */
 };
 
 /* Argument-validation errors (negative so they cannot collide with hipError_t). */
@@ -79,7 +79,8 @@ enum {
  *
  * Supported: f32 inputs, any dHead <= 256, any seqLen (exact-fp32 path);
  *            bf16 inputs, dHead in {64,128} on the MFMA path (any seqLen >= 1), other dHead
- *            <= 256 on the generic path; fp8 e4m3fn inputs, dHead in {64,128}.
+ *            <= 256 on the generic path; fp8 e4m3fn inputs, dHead = 128 (QK^T on the fp8 MFMA).
+ *            One head's K/V extent (seqLen x row stride) must stay below 2^31 bytes on the MFMA paths.
  */
 int flash_attention(const void* Q, const void* K, const void* V, void* O,
                     int batchSize, int numHeads, int seqLen, int dHead,
@@ -103,6 +104,18 @@ int flash_attention_strided(const void* Q, const void* K, const void* V, void* O
                             float scale, bool is_causal, int dtype, int o_dtype,
                             const fa_strides* sQ, const fa_strides* sK, const fa_strides* sV,
                             const fa_strides* sO, void* stream);
+
+/*
+ * flash_attention_lse -- flash_attention() that also returns the log-sum-exp of every softmax row:
+ *     LSE[b,h,q] = ln( sum over visible keys k of exp(scale * <Q[b,h,q], K[b,h,k]>) )      (natural log)
+ * in a dense fp32 [batchSize, numHeads, seqLen] device buffer (16-byte aligned).  This is the L / M
+ * statistic of the reference's commented-out first API (kernels/FlashAttention.cuh:21,
+ * archive/archive.cu:34-42,201-204) and what a backward pass, split-KV or ring composition needs.
+ * LSE may be NULL (then identical to flash_attention()).
+ */
+int flash_attention_lse(const void* Q, const void* K, const void* V, void* O, float* LSE,
+                        int batchSize, int numHeads, int seqLen, int dHead,
+                        float scale, bool is_causal, int dtype, int o_dtype, void* stream);
 
 /*
  * Launch-geometry policy -- the counterpart of the reference's helpers.hpp:8-36

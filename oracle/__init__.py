@@ -155,6 +155,19 @@ def mha_numpy(Q, K, V, num_heads):
     return out, attn
 
 
+def lse_numpy(Q, K, scale=None, causal=False):
+    """ln sum_k exp(scale * <q, k>) over the visible keys, float64 -> [..., S]."""
+    Q, K = (np.asarray(a, dtype=np.float64) for a in (Q, K))
+    S, d = Q.shape[-2:]
+    if scale is None:
+        scale = 1.0 / np.sqrt(d)
+    s = Q @ np.swapaxes(K, -1, -2) * scale
+    if causal:
+        s = np.where(np.triu(np.ones((S, S), dtype=bool), 1), -np.inf, s)
+    mx = s.max(axis=-1, keepdims=True)
+    return (mx + np.log(np.exp(s - mx).sum(axis=-1, keepdims=True)))[..., 0]
+
+
 def attention_numpy(Q, K, V, scale=None, causal=False):
     """Dense [B,H,S,d] attention in numpy float64; causal masks key k > query q
     (tests/main.cu:81, kernels/utils.cuh:43)."""

@@ -221,6 +221,25 @@ def test_fp8_golden_inputs(golden):
     check(O[0, 0, :, :64].cpu().numpy(), golden.load("F5e4m3", "out")[0], 4e-3, 4e-3, rms=1e-3)
 
 
+@pytest.mark.parametrize("dtype,d,S,causal", [(torch.bfloat16, 128, 777, True), (torch.bfloat16, 64, 512, False),
+                                              (torch.float32, 40, 100, True), (torch.bfloat16, 128, 1536, False)])
+def test_lse_output(dtype, d, S, causal):
+    """flash_attention_lse: LSE[b,h,q] = ln sum_k exp(scale*q.k) (the L/M statistic of the reference's
+    commented-out first API, kernels/FlashAttention.cuh:21).  Also through the optimistic pass with a
+    large reference offset (Q, K x4) and its fallback (x12)."""
+    B, H = 2, 2
+    Q, K, V = (randn((B, H, S, d), s, dtype) for s in (70, 71, 72))
+    for mul in ((1.0, 4.0, 12.0) if dtype == torch.bfloat16 else (1.0,)):
+        Qm, Km = (Q.float() * mul).to(dtype), (K.float() * mul).to(dtype)
+        O, lse = fa.flash_attention(Qm.to(DEV), Km.to(DEV), V.to(DEV), is_causal=causal, out_dtype=torch.float32,
+                                    return_lse=True)
+        torch.cuda.synchronize()
+        ref = oracle.lse_numpy(Qm.float().numpy(), Km.float().numpy(), causal=causal)
+        np.testing.assert_allclose(lse.cpu().numpy(), ref, rtol=2e-5, atol=2e-4 * mul * mul)
+        refO = oracle.attention(Qm.float().numpy(), Km.float().numpy(), V.float().numpy(), causal=causal)
+        check(O.cpu().numpy(), refO, 1.6e-2, 1.6e-2)
+
+
 def test_heads_are_independent():
     """Reference defect D2 (every query attends to every batch/head) must not be reproduced:
     a head computed alone equals the same head computed inside a batch, bit for bit."""
@@ -257,6 +276,33 @@ def test_runs_on_a_side_stream_and_is_deterministic():
     st.synchronize()
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+def test_call_is_graph_capturable():
+    """The launcher allocates nothing and never synchronises (include/flash_attention.h contract), so a call
+    can be captured into a HIP graph and replayed on new data."""
+    Q, K, V = (randn((2, 4, 512, 128), s, torch.bfloat16).to(DEV) for s in (80, 81, 82))
+    O = torch.empty_like(Q)
+    fa.flash_attention(Q, K, V, O, is_causal=True)           # warm-up outside capture (raises the LDS limit once)
+    torch.cuda.synchronize()
+    expected = O.clone()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        O.zero_()
+        with torch.cuda.graph(graph, stream=st):
+            fa.flash_attention(Q, K, V, O, is_causal=True)
+    torch.cuda.current_stream().wait_stream(st)
+    O.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(O, expected)
+    Q.copy_(randn((2, 4, 512, 128), 83, torch.bfloat16))     # new data through the same graph
+    graph.replay()
+    torch.cuda.synchronize()
+    ref = oracle.attention(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), causal=True)
+    check(O.float().cpu().numpy(), ref, 8e-3, 8e-3)
 
 
 # ------------------------------------------------------------------ BASELINE sizes
