@@ -6,7 +6,7 @@
 // (updateSoftmaxState), :93-113 (multiplyVAccumulateO).  Same algorithm -- blocked scores, running
 // (max, sum) per query row, rescaled accumulation of P.V -- re-designed for CDNA4:
 //
-//   * one WAVE owns 32 query rows (the reference: one warp per row); a KV tile is 64 keys;
+//   * one WAVE owns R groups of 32 query rows (the reference: one warp per row); a KV tile is 64 keys;
 //   * scores come from v_mfma_f32_32x32x16_{bf16, fp8_fp8} in the SWAPPED orientation S^T = K.Q^T, so
 //     the 32 scores of one query row and key half sit in ONE lane's registers: row max / row sum are
 //     in-lane ops plus one v_permlane32_swap (the reference: cg::reduce + Bc-1 shuffles, utils.cuh:66-73);
@@ -14,187 +14,235 @@
 //     every tile, utils.cuh:75-80); exp is exp2 with scale*log2(e) folded into one FMA;
 //   * P^T (accumulator layout: key in the register index, query on the lane), rounded to bf16, IS the
 //     B operand of O^T += V^T.P^T; V^T fragments come from ds_read_b64_tr_b16.  O lives in 16*D/32
-//     accumulator registers (the reference keeps O in shared memory, utils.cuh:107-111).
+//     accumulator registers per row group (the reference keeps O in shared memory, utils.cuh:107-111).
 //
 // Schedule.  hipcc, left alone (or nudged with sched_group_barrier), hoists the whole softmax in front
 // of the MFMAs and makes each QK^T MFMA wait on an LDS read issued just before it.  A tile is therefore
-// cut into NA + NB slots, one MFMA each, fenced by __builtin_amdgcn_sched_barrier(0); iteration t of a wave:
+// cut into (NA + NB)*R slots, one MFMA each, fenced by __builtin_amdgcn_sched_barrier(0); iteration t:
 //
-//   A_i (NA = 2*D/16): MFMA  S(t+1) += Kfrag . Qfrag          (QK^T of the NEXT tile, K(t+1) in LDS)
-//                      read  K fragment NPRE ahead (later: the first V^T fragments)
-//                      [buffer_load #n of tile t+2 at i = 1+2n]
-//                      VALU  exp2 / row sum / bf16 pack of this slot's share of P(t)
-//   B_j (NB = 4*D/32): MFMA  O^T += V^T(t)frag . P(t)frag
-//                      read  V^T fragment VPRE ahead (2 x ds_read_b64_tr_b16)
-//                      VALU  rest of P(t); tracked pass: v_max3 of S(t+1) for j < NB/2, decision at j = NB/2
-//                      [ds_write_b128 #n of tile t+2 at j = NB/2 + 2n]
+//   A_i (NA*R, NA = 2*D/16): MFMA  S_r(t+1) += Kfrag . Qfrag_r     (QK^T of the NEXT tile, K(t+1) in LDS;
+//                                  each K fragment serves the R row groups back to back)
+//                            read  K fragment NPRE ahead (later: the first V^T fragments)
+//                            [buffer_load #n of tile t+2 at i = 1+2n]
+//                            VALU  exp2 / row sum / bf16 pack of this slot's share of P(t)
+//   B_j (NB*R, NB = 4*D/32): MFMA  O_r^T += V^T(t)frag . P_r(t)frag  (each V^T fragment serves R groups)
+//                            read  V^T fragment VPRE ahead (2 x ds_read_b64_tr_b16)
+//                            VALU  rest of P(t); tracked pass: v_max3 of S(t+1) in the first half, then the decision
+//                            [ds_write_b128 #n of tile t+2 at j = NB*R/2 + 2n]
 //
-// Score element e of the 32 a lane holds goes to overall slot e*(NA + 3*NB/4)/32, which meets the
-// deadlines "P group g (elements 8g..8g+7) complete before PV slot g*NB/4" with <= 1.25 elements per
-// 32-cycle MFMA gap at d = 128.  Empty asm statements pin the partial sums / maxima in their slot
-// (hipcc otherwise sinks them behind the MFMAs).
+// The 32*R score elements of a lane are ordered (key group g, row group r, j) and element E goes to
+// overall slot E*SPAN/(32R), SPAN = (NA + 3*NB/4)*R, which meets "P group (g, r) complete before its PV
+// slot" with <= 1.25 elements per 32-cycle MFMA gap at d = 128.  Empty asm statements pin the partial
+// sums / maxima in their slot (hipcc otherwise sinks them behind the MFMAs).
 #pragma once
 
 #include "loaders.hip.h"
 
 namespace fa {
 
+template <int R>
+struct Scores {          // raw scores of one 64-key tile: [row group][32-key half]
+    f32x16 s[R][2];
+};
+
 template <class C>
 struct WaveCompute {
-    static constexpr int D = C::D, ESZ = C::ESZ;
+    static constexpr int D = C::D, ESZ = C::ESZ, R = C::R;
     static constexpr int KS = D / 16;              // MFMA k-steps of one 32-key half of QK^T
     static constexpr int DB = D / 32;              // 32-wide d blocks of O^T
-    static constexpr int NA = 2 * KS, NB = 4 * DB; // slots of phase A / phase B
-    static constexpr int MPF = ESZ == 1 ? 2 : 1;   // MFMAs fed by one 16-byte K (or Q) fragment
+    static constexpr int NA = 2 * KS, NB = 4 * DB; // MFMAs per row group in phase A / phase B
+    static constexpr int SA = NA * R, SB = NB * R; // slots of phase A / phase B
+    static constexpr int MPF = ESZ == 1 ? 2 : 1;   // MFMAs (per row group) fed by one 16-byte K / Q fragment
     static constexpr int NF = NA / MPF;            // K fragment reads per tile
-    static constexpr int FPH = NF / 2;             // ... per 32-key half = Q fragment count
+    static constexpr int FPH = NF / 2;             // ... per 32-key half = Q fragments per row group
     static constexpr int NPRE = C::NPRE < NF ? C::NPRE : NF;
     static constexpr int VPRE = C::VPRE;
-    static constexpr int SPAN = NA + (3 * NB) / 4; // overall slots the exponentials are spread over
+    static constexpr int NE = 32 * R;              // score elements per lane per tile
+    static constexpr int SPAN = SA + (3 * SB) / 4; // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
-    using Stage = BufStage<D, ESZ>;
+    using Stage = BufStage<D, ESZ, 8 / R>;
     static constexpr int NL = Stage::NL, NW = Stage::NW;
+    static_assert(2 * NL <= SA && 2 * NW <= SB / 2 + 1, "staging does not fit the slot plan");
 
     // ---- state that lives across tiles ----
-    u32x4 qf[FPH];     // Q fragments (16 bytes each: one bf16 MFMA operand, or two fp8 operands)
-    f32x16 o[DB];      // O^T accumulators: row = d, col = query
-    float m;           // reference max used for exponentiation (scaled, log2 domain)
-    float l;           // partial row sum (this lane's key half)
+    u32x4 qf[R][FPH];  // Q fragments (16 bytes each: one bf16 MFMA operand, or two fp8 operands)
+    f32x16 o[R][DB];   // O^T accumulators: row = d, col = query
+    float m[R];        // reference max used for exponentiation (scaled, log2 domain)
+    float l[R];        // partial row sum (this lane's key half)
     // ---- per-tile scratch ----
     u32x4 kf[NPRE];    // K fragment window
     bf16x8 vf[VPRE + 1];
-    uint32_t pw[16];   // P(t) as packed bf16 pairs: word 4g+w = elements 8g+2w, 8g+2w+1
-    float sum_a, sum_b, mx_a, mx_b, p_even;
+    uint32_t pw[R][16];   // P(t) as packed bf16 pairs: word 4g+w = elements 8g+2w, 8g+2w+1
+    float sum_a[R], sum_b[R], mx_a[R], mx_b[R], p_even;
     bool need;         // tracked pass: lazy-rescale decision for S(t+1)
     unsigned long long t_mid = 0, t_end = 0;   // STAMP builds only
 
-    __host__ __device__ static constexpr int elem_slot(int e) { return e * SPAN / 32; }
+    __host__ __device__ static constexpr int elem_slot(int E) { return E * SPAN / NE; }
 
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int i = 0; i < DB; ++i)
+        for (int r = 0; r < R; ++r) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-        m = -INFINITY;
-        l = 0.f;
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) o[r][i][k] = 0.f;
+            m[r] = -INFINITY;
+            l[r] = 0.f;
+        }
     }
 
     // Q fragment u of row q: 16 bytes at byte 32u + 16h of the row.  bf16: d = 16u + 8h .. +7 (k-step u).
     // fp8: d = 32u + 16h .. +15 -- the contraction order is permuted the same way for K (chunk 2u+h of
     // the K image), so one 16-byte fragment feeds two MFMAs.
     __device__ __forceinline__ void load_q(const char* Qh, int64_t qS_bytes, int row0, int S, int lane) {
-        int r = row0 + (lane & 31);
-        r = r < S ? r : S - 1;
-        const char* src = Qh + r * qS_bytes + (lane >> 5) * 16;
 #pragma unroll
-        for (int u = 0; u < FPH; ++u) qf[u] = *reinterpret_cast<const u32x4*>(src + u * 32);
+        for (int r = 0; r < R; ++r) {
+            int row = row0 + 32 * r + (lane & 31);
+            row = row < S ? row : S - 1;
+            const char* src = Qh + row * qS_bytes + (lane >> 5) * 16;
+#pragma unroll
+            for (int u = 0; u < FPH; ++u) qf[r][u] = *reinterpret_cast<const u32x4*>(src + u * 32);
+        }
     }
     // Make the Q fragments look "consumed" so hipcc waits for their loads HERE and not with a
     // pessimistic vmcnt inside the main loop (where it would also drain the tile prefetch).
     __device__ __forceinline__ void pin_q() {
 #pragma unroll
-        for (int u = 0; u < FPH; ++u) asm volatile("" : "+v"(qf[u]));
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int u = 0; u < FPH; ++u) {
+                if constexpr (C::ASM_MFMA) asm volatile("" : "+a"(qf[r][u]));   // Q's home is the accumulator file
+                else asm volatile("" : "+v"(qf[r][u]));
+            }
     }
 
     __device__ __forceinline__ u32x4 k_read(lds_ptr kimg, int kbase, int f) const {
         return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + (f % FPH) * 2048 + (f / FPH) * 512));
     }
-    // MFMA #i of QK^T (i = MPF*f + sub) from K fragment kfrag (= fragment f)
-    template <int I>
-    __device__ __forceinline__ void qk_mfma(const u32x4& kfrag, f32x16& n0, f32x16& n1) const {
-        constexpr int f = I / MPF, sub = I % MPF;
-        const u32x4& q = qf[f % FPH];
-        f32x16& acc = (f < FPH) ? n0 : n1;
-        if constexpr (ESZ == 2) {
+    // QK^T MFMA of fragment f, sub-step sub (fp8 only), row group r
+    template <int F, int SUB, int RG>
+    __device__ __forceinline__ void qk_mfma(const u32x4& kfrag, Scores<R>& n) const {
+        const u32x4& q = qf[RG][F % FPH];
+        f32x16& acc = n.s[RG][F / FPH];
+        constexpr bool first = (F % FPH == 0) && SUB == 0;   // first MFMA of this accumulation chain
+        if constexpr (C::ASM_MFMA) {
+            if constexpr (ESZ == 2) {
+                mfma_qk_asm<first>(acc, kfrag, q);
+            } else {
+                const uint64_t a = (uint64_t)kfrag[2 * SUB] | ((uint64_t)kfrag[2 * SUB + 1] << 32);
+                const uint64_t b = (uint64_t)q[2 * SUB] | ((uint64_t)q[2 * SUB + 1] << 32);
+                mfma_qk_fp8_asm<first>(acc, a, b);
+            }
+        } else if constexpr (ESZ == 2) {
             acc = mfma_32x32x16(__builtin_bit_cast(bf16x8, kfrag), __builtin_bit_cast(bf16x8, q), acc);
         } else {
-            const uint64_t a = (uint64_t)kfrag[2 * sub] | ((uint64_t)kfrag[2 * sub + 1] << 32);
-            const uint64_t b = (uint64_t)q[2 * sub] | ((uint64_t)q[2 * sub + 1] << 32);
+            const uint64_t a = (uint64_t)kfrag[2 * SUB] | ((uint64_t)kfrag[2 * SUB + 1] << 32);
+            const uint64_t b = (uint64_t)q[2 * SUB] | ((uint64_t)q[2 * SUB + 1] << 32);
             acc = mfma_32x32x16_fp8(a, b, acc);
         }
     }
-
-    // S^T(both 32-key halves) = K.Q^T, compiler-scheduled: used once per pass for tile 0.
-    template <int I = 0>
-    __device__ __forceinline__ void qk_all(lds_ptr kimg, int kbase, f32x16& s0, f32x16& s1) {
-        if constexpr (I == 0) {
+    __device__ __forceinline__ static void zero(Scores<R>& n) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-        }
-        if constexpr (I < NA) {
-            if constexpr (I % MPF == 0) kf[0] = k_read(kimg, kbase, I / MPF);
-            qk_mfma<I>(kf[0], s0, s1);
-            qk_all<I + 1>(kimg, kbase, s0, s1);
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { n.s[r][0][k] = 0.f; n.s[r][1][k] = 0.f; }
+    }
+
+    // S^T = K.Q^T for all row groups, compiler-scheduled: used once per pass for tile 0.
+    template <int I = 0>
+    __device__ __forceinline__ void qk_all(lds_ptr kimg, int kbase, Scores<R>& n) {
+        if constexpr (I == 0 && !C::ASM_MFMA) zero(n);
+        if constexpr (I < SA) {
+            constexpr int f = I / (MPF * R), sub = (I % (MPF * R)) / R, rg = I % R;
+            if constexpr (I % (MPF * R) == 0) kf[0] = k_read(kimg, kbase, f);
+            qk_mfma<f, sub, rg>(kf[0], n);
+            qk_all<I + 1>(kimg, kbase, n);
         }
     }
 
     // Diagonal / ragged tile: key index > query index, or key index >= S  ->  -inf.
-    // s0[r] holds key kv0 + acc_row(r,h), s1[r] key kv0 + 32 + acc_row(r,h); query q_row0 + (lane&31).
-    __device__ __forceinline__ void mask(f32x16& s0, f32x16& s1, int kv0, int q_row0, int S, int lane) const {
-        const int qi = q_row0 + (lane & 31);
-        const int lim = C::CAUSAL ? (qi < S - 1 ? qi : S - 1) : S - 1;
+    // s[r][0][k] holds key kv0 + acc_row(k,h), s[r][1][k] key kv0 + 32 + acc_row(k,h); query q_row0 + 32r + (lane&31).
+    __device__ __forceinline__ void mask(Scores<R>& n, int kv0, int q_row0, int S, int lane) const {
+        if constexpr (C::ASM_MFMA) mfma_drain();
         const int k0 = kv0 + 4 * (lane >> 5);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = (k0 + acc_row(r, 0)) > lim ? -INFINITY : s0[r];
-            s1[r] = (k0 + 32 + acc_row(r, 0)) > lim ? -INFINITY : s1[r];
+        for (int r = 0; r < R; ++r) {
+            const int qi = q_row0 + 32 * r + (lane & 31);
+            const int lim = C::CAUSAL ? (qi < S - 1 ? qi : S - 1) : S - 1;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                n.s[r][0][k] = (k0 + acc_row(k, 0)) > lim ? -INFINITY : n.s[r][0][k];
+                n.s[r][1][k] = (k0 + 32 + acc_row(k, 0)) > lim ? -INFINITY : n.s[r][1][k];
+            }
         }
     }
-    __device__ __forceinline__ float row_max(const f32x16& s0, const f32x16& s1) const {
-        float a = fmaxf(s0[0], s0[1]), b = fmaxf(s1[0], s1[1]);
+    __device__ __forceinline__ float row_max(const Scores<R>& n, int r) const {
+        float a = fmaxf(n.s[r][0][0], n.s[r][0][1]), b = fmaxf(n.s[r][1][0], n.s[r][1][1]);
 #pragma unroll
-        for (int r = 2; r < 16; r += 2) {
-            a = fmaxf(a, fmaxf(s0[r], s0[r + 1]));
-            b = fmaxf(b, fmaxf(s1[r], s1[r + 1]));
+        for (int k = 2; k < 16; k += 2) {
+            a = fmaxf(a, fmaxf(n.s[r][0][k], n.s[r][0][k + 1]));
+            b = fmaxf(b, fmaxf(n.s[r][1][k], n.s[r][1][k + 1]));
         }
         return fmaxf(a, b);
     }
-    // Tile 0 of a pass: m = its row max (m = -inf before, so alpha = 0 and O, l stay 0).
-    __device__ __forceinline__ void first_max(float mx_raw, float c) { m = fmaxf(m, max_both_halves(mx_raw) * c); }
+    // Tile 0 of a pass: m = its row max (m = -inf before; O and l are still 0).
+    __device__ __forceinline__ void first_max(const Scores<R>& n, float c) {
+        if constexpr (C::ASM_MFMA) mfma_drain();
+#pragma unroll
+        for (int r = 0; r < R; ++r) m[r] = fmaxf(m[r], max_both_halves(row_max(n, r)) * c);
+    }
 
     // ---- softmax slices ------------------------------------------------------------------------
+    // Element E (0..32R-1) = (key group g = E/(8R), row group r = (E/8)%R, j = E%8) -> score 8g+j of row group r.
     template <int E>
-    __device__ __forceinline__ void exp_elem(const f32x16& c0, const f32x16& c1, float c) {
-        const float x = E < 16 ? c0[E & 15] : c1[E & 15];
-        const float p = fast_exp2(fmaf(x, c, -m));
-        if constexpr (E & 1) {
-            sum_b += p;
-            pw[E >> 1] = pack_bf16(p_even, p);
-            asm volatile("" : "+v"(sum_a), "+v"(sum_b));   // keep the adds in this slot (hipcc sinks them)
+    __device__ __forceinline__ void exp_elem(const Scores<R>& cur, float c) {
+        constexpr int g = E / (8 * R), r = (E / 8) % R, j = E % 8, e = 8 * g + j;
+        const float x = cur.s[r][e >> 4][e & 15];
+        const float p = fast_exp2(fmaf(x, c, -m[r]));
+        if constexpr (e & 1) {
+            sum_b[r] += p;
+            pw[r][e >> 1] = pack_bf16(p_even, p);
+            asm volatile("" : "+v"(sum_a[r]), "+v"(sum_b[r]));   // keep the adds in this slot (hipcc sinks them)
         } else {
-            sum_a += p;
+            sum_a[r] += p;
             p_even = p;
         }
     }
     template <int SLOT, int E = 0>
-    __device__ __forceinline__ void exp_slot(const f32x16& c0, const f32x16& c1, float c) {
-        if constexpr (E < 32) {
-            if constexpr (elem_slot(E) == SLOT) exp_elem<E>(c0, c1, c);
-            exp_slot<SLOT, E + 1>(c0, c1, c);
+    __device__ __forceinline__ void exp_slot(const Scores<R>& cur, float c) {
+        if constexpr (E < NE) {
+            if constexpr (elem_slot(E) == SLOT) exp_elem<E>(cur, c);
+            exp_slot<SLOT, E + 1>(cur, c);
         }
     }
-    __device__ __forceinline__ bf16x8 p_frag(int g) const {
-        u32x4 v = {pw[4 * g], pw[4 * g + 1], pw[4 * g + 2], pw[4 * g + 3]};
+    __device__ __forceinline__ bf16x8 p_frag(int r, int g) const {
+        u32x4 v = {pw[r][4 * g], pw[r][4 * g + 1], pw[r][4 * g + 2], pw[r][4 * g + 3]};
         return __builtin_bit_cast(bf16x8, v);
     }
-    // tracked pass: v_max3 chain over 64/NB values of S(t+1) in slot J (J < NB/2)
+    // tracked pass: v_max3 chains over 64/NB values of S(t+1) in slot J (J < SB/2); 32R values in all
     template <int J>
-    __device__ __forceinline__ void max3_slot(const f32x16& n0, const f32x16& n1) {
+    __device__ __forceinline__ void max3_slot(const Scores<R>& n) {
         constexpr int PER = 64 / NB;
 #pragma unroll
         for (int k = 0; k < PER; k += 2) {
-            const int e = J * PER + k;
-            const float x0 = e < 16 ? n0[e & 15] : n1[e & 15];
-            const float x1 = (e + 1) < 16 ? n0[(e + 1) & 15] : n1[(e + 1) & 15];
-            if ((k >> 1) & 1) mx_b = fmaxf(fmaxf(mx_b, x0), x1);
-            else mx_a = fmaxf(fmaxf(mx_a, x0), x1);
+            const int E = J * PER + k, r = E / 32, e = E % 32;
+            const float x0 = n.s[r][e >> 4][e & 15];
+            const float x1 = n.s[r][(e + 1) >> 4][(e + 1) & 15];
+            if ((k >> 1) & 1) mx_b[r] = fmaxf(fmaxf(mx_b[r], x0), x1);
+            else mx_a[r] = fmaxf(fmaxf(mx_a[r], x0), x1);
         }
-        asm volatile("" : "+v"(mx_a), "+v"(mx_b));
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("" : "+v"(mx_a[r]), "+v"(mx_b[r]));
     }
     __device__ __forceinline__ void decide(float c) {
-        const float mx = max_both_halves(fmaxf(mx_a, mx_b)) * c;
-        need = __any(mx > m + (float)C::THR);
-        mx_a = mx;   // keep the scaled row max for the rescale body
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float mx = max_both_halves(fmaxf(mx_a[r], mx_b[r])) * c;
+            any = any || (mx > m[r] + (float)C::THR);
+            mx_a[r] = mx;   // keep the scaled row max for the rescale body
+        }
+        need = __any(any);
     }
 
     // V^T A-fragment of 16-key step s4, d block db: two transposed reads.  Element j of lane half h is
@@ -207,39 +255,49 @@ struct WaveCompute {
     }
 
     // ---- the slots -----------------------------------------------------------------------------
+    // phase A slot I: fragment f = I/(MPF*R), then (sub, row group) = ((I % (MPF*R)) / R, I % R)
     template <int I>
     __device__ __forceinline__ void slots_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase,
-                                            float c, const f32x16& c0, const f32x16& c1, f32x16& n0, f32x16& n1) {
-        if constexpr (I < NA) {
-            constexpr int f = I / MPF;
-            qk_mfma<I>(kf[f % NPRE], n0, n1);
-            if constexpr (I % MPF == MPF - 1 && f + NPRE < NF) kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
-            if constexpr (I >= NA - VPRE) {   // the last VPRE phase-A slots start the V^T window of phase B
-                constexpr int J = I - (NA - VPRE);
-                vf[J % (VPRE + 1)] = v_frag(v_cur, vbase, J / DB, J % DB);
+                                            float c, const Scores<R>& cur, Scores<R>& nxt) {
+        if constexpr (I < SA) {
+            constexpr int f = I / (MPF * R), rem = I % (MPF * R), sub = rem / R, rg = rem % R;
+            if constexpr (C::VALU_FIRST) exp_slot<I>(cur, c);   // softmax slice covers the fragment's LDS latency
+            qk_mfma<f, sub, rg>(kf[f % NPRE], nxt);
+            if constexpr (rem == MPF * R - 1 && f + NPRE < NF) kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
+            if constexpr (I >= SA - VPRE) {   // the last VPRE phase-A slots start the V^T window of phase B
+                constexpr int v = I - (SA - VPRE);
+                vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DB, v % DB);
             }
             if constexpr ((I & 1) && (I >> 1) < NL) st.template load<(I >> 1)>(t_load);
-            exp_slot<I>(c0, c1, c);
+            if constexpr (!C::VALU_FIRST) exp_slot<I>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
-            slots_a<I + 1>(st, t_load, k_next, v_cur, kbase, vbase, c, c0, c1, n0, n1);
+            slots_a<I + 1>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         }
     }
+    // phase B slot J: V^T fragment v = J/R (16-key step v/DB, d block v%DB), row group J%R
     template <bool TRACK, int J>
     __device__ __forceinline__ void slots_b(const Stage& st, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
-                                            const f32x16& c0, const f32x16& c1, const f32x16& n0, const f32x16& n1) {
-        if constexpr (J < NB) {
-            o[J % DB] = mfma_32x32x16(vf[J % (VPRE + 1)], p_frag(J / DB), o[J % DB]);
-            if constexpr (J + VPRE < NB) {
-                constexpr int JN = J + VPRE;
-                vf[JN % (VPRE + 1)] = v_frag(v_cur, vbase, JN / DB, JN % DB);
+                                            const Scores<R>& cur, const Scores<R>& nxt) {
+        if constexpr (J < SB) {
+            constexpr int v = J / R, rg = J % R, s4 = v / DB, db = v % DB;
+            if constexpr (C::ASM_MFMA) {
+                // pad when the last bf16 pack of P group (s4, rg) was issued in the slot just before this one
+                constexpr int e_last = (s4 * R + rg) * 8 + 7;
+                mfma_pv_asm<(elem_slot(e_last) >= SA + J - 1)>(o[rg][db], vf[v % (VPRE + 1)], p_frag(rg, s4));
+            } else {
+                o[rg][db] = mfma_32x32x16(vf[v % (VPRE + 1)], p_frag(rg, s4), o[rg][db]);
             }
-            exp_slot<NA + J>(c0, c1, c);
-            if constexpr (TRACK && J < NB / 2) max3_slot<J>(n0, n1);
-            if constexpr (TRACK && J == NB / 2) decide(c);
-            if constexpr (J >= NB / 2 && ((J - NB / 2) & 1) == 0 && (J - NB / 2) / 2 < NW)
-                st.template write<(J - NB / 2) / 2>(wr_slot);
+            if constexpr (rg == R - 1 && v + VPRE < NB) {
+                constexpr int vn = v + VPRE;
+                vf[vn % (VPRE + 1)] = v_frag(v_cur, vbase, vn / DB, vn % DB);
+            }
+            exp_slot<SA + J>(cur, c);
+            if constexpr (TRACK && J < SB / 2) max3_slot<J>(nxt);
+            if constexpr (TRACK && J == SB / 2) decide(c);
+            if constexpr (J >= SB / 2 && ((J - SB / 2) & 1) == 0 && (J - SB / 2) / 2 < NW)
+                st.template write<(J - SB / 2) / 2>(wr_slot);
             __builtin_amdgcn_sched_barrier(0);
-            slots_b<TRACK, J + 1>(st, wr_slot, v_cur, vbase, c, c0, c1, n0, n1);
+            slots_b<TRACK, J + 1>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         }
     }
 
@@ -250,129 +308,149 @@ struct WaveCompute {
     // pass -- m stays the row max of tile 0 and no max / decision / rescale is issued.
     template <bool TRACK>
     __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
-                                              int kbase, int vbase, float c, const f32x16& cur0, const f32x16& cur1,
-                                              f32x16& nxt0, f32x16& nxt1, bool has_next, bool mask_next, int kv0_next,
-                                              int q_row0, int S, int lane) {
-        sum_a = sum_b = 0.f;
-        mx_a = mx_b = -INFINITY;
+                                              int kbase, int vbase, float c, const Scores<R>& cur, Scores<R>& nxt,
+                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { nxt0[r] = 0.f; nxt1[r] = 0.f; }
+        for (int r = 0; r < R; ++r) {
+            sum_a[r] = sum_b[r] = 0.f;
+            mx_a[r] = mx_b[r] = -INFINITY;
+        }
+        if constexpr (!C::ASM_MFMA) zero(nxt);   // asm form: the first MFMA of each chain has C = 0
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
         __builtin_amdgcn_sched_barrier(0);
-        slots_a<0>(st, t_load, k_next, v_cur, kbase, vbase, c, cur0, cur1, nxt0, nxt1);
+        slots_a<0>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_mid = cycle_stamp();
-        slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur0, cur1, nxt0, nxt1);
+        slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
-        l += sum_a + sum_b;
+#pragma unroll
+        for (int r = 0; r < R; ++r) l[r] += sum_a[r] + sum_b[r];
         // ONE rescale site: the masked (diagonal / ragged) tile only recomputes the scalar decision and
         // the row max.  (Two sites that both multiply O made hipcc copy all 64 accumulator registers
         // twice per tile on the common path.)
         if (has_next && mask_next) {
-            mask(nxt0, nxt1, kv0_next, q_row0, S, lane);
+            mask(nxt, kv0_next, q_row0, S, lane);
             if constexpr (TRACK) {
-                mx_a = row_max(nxt0, nxt1);
-                mx_b = mx_a;
+#pragma unroll
+                for (int r = 0; r < R; ++r) { mx_a[r] = row_max(nxt, r); mx_b[r] = mx_a[r]; }
                 decide(c);
             }
         }
         if constexpr (TRACK) {
             if (has_next && need) {
-                const float mn = fmaxf(m, mx_a);
-                const float alpha = fast_exp2(m - mn);
-                m = mn;
-                l *= alpha;
+                if constexpr (C::ASM_MFMA) mfma_drain();   // O was just written by asm MFMAs
 #pragma unroll
-                for (int i = 0; i < DB; ++i)
+                for (int r = 0; r < R; ++r) {
+                    const float mn = fmaxf(m[r], mx_a[r]);
+                    const float alpha = fast_exp2(m[r] - mn);
+                    m[r] = mn;
+                    l[r] *= alpha;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                    for (int i = 0; i < DB; ++i)
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) o[r][i][k] *= alpha;
+                }
             }
         }
     }
 
-    // True iff this lane's row sum or any of its O accumulators is inf / NaN (x*0 is NaN for both).
+    // True iff a row sum or any O accumulator of this lane is inf / NaN (x*0 is NaN for both).
     __device__ __forceinline__ bool not_finite() const {
-        float acc = l * 0.f;
+        if constexpr (C::ASM_MFMA) mfma_drain();
+        float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < DB; ++i)
+        for (int r = 0; r < R; ++r) {
+            acc = fmaf(l[r], 0.f, acc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc = fmaf(o[i][r], 0.f, acc);
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc = fmaf(o[r][i][k], 0.f, acc);
+        }
         return acc != acc;
     }
 
     // ---- epilogues -----------------------------------------------------------------------------
-    // Direct form: divide by the row sum and store O[q][d].  A lane holds d = 32db + 8g4 + 4h + (0..3).
-    // Used for 4-byte outputs (the reference's float* O).
     // ln sum_k exp(scale*s_k) = (m + log2 l) * ln 2   (m is the reference max in the scaled log2 domain)
-    __device__ __forceinline__ void store_lse(float* lse_head, float l_tot, int row0, int S, int lane) const {
+    __device__ __forceinline__ void store_lse(float* lse_head, float l_tot, int r, int row0, int S, int lane) const {
         const int qi = row0 + (lane & 31);
-        if (lse_head && lane < 32 && qi < S) lse_head[qi] = (m + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+        if (lse_head && lane < 32 && qi < S) lse_head[qi] = (m[r] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
     }
 
+    // Direct form: divide by the row sum and store O[q][d].  A lane holds d = 32db + 8g4 + 4h + (0..3).
+    // Used for 4-byte outputs (the reference's float* O).  row0 = first row of the WAVE.
     template <typename OutT>
     __device__ __forceinline__ void store_o(char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S, int lane) {
-        const float l_tot = sum_both_halves(l);
-        store_lse(lse_head, l_tot, row0, S, lane);
-        const float inv = 1.0f / l_tot;
-        const int qi = row0 + (lane & 31);
-        const int h = lane >> 5;
-        if (qi >= S) return;
-        char* dst = Oh + qi * oS_bytes;
+        if constexpr (C::ASM_MFMA) mfma_drain();
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int r = 0; r < R; ++r) {
+            const float l_tot = sum_both_halves(l[r]);
+            store_lse(lse_head, l_tot, r, row0 + 32 * r, S, lane);
+            const float inv = 1.0f / l_tot;
+            const int qi = row0 + 32 * r + (lane & 31);
+            const int h = lane >> 5;
+            if (qi < S) {
+                char* dst = Oh + qi * oS_bytes;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = 32 * db + 8 * g4 + 4 * h;
-                const float a = o[db][4 * g4 + 0] * inv, b = o[db][4 * g4 + 1] * inv;
-                const float c2 = o[db][4 * g4 + 2] * inv, e = o[db][4 * g4 + 3] * inv;
-                if constexpr (sizeof(OutT) == 4) {
-                    f32x4 v = {a, b, c2, e};
-                    *reinterpret_cast<f32x4*>(dst + d0 * 4) = v;
-                } else if constexpr (__is_same(OutT, __bf16)) {
-                    u32x2 v = {pack_bf16(a, b), pack_bf16(c2, e)};
-                    *reinterpret_cast<u32x2*>(dst + d0 * 2) = v;
-                } else {
-                    u32x2 v = {pack_f16(a, b), pack_f16(c2, e)};
-                    *reinterpret_cast<u32x2*>(dst + d0 * 2) = v;
-                }
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int d0 = 32 * db + 8 * g4 + 4 * h;
+                        const float a = o[r][db][4 * g4 + 0] * inv, b = o[r][db][4 * g4 + 1] * inv;
+                        const float c2 = o[r][db][4 * g4 + 2] * inv, e = o[r][db][4 * g4 + 3] * inv;
+                        if constexpr (sizeof(OutT) == 4) {
+                            f32x4 v = {a, b, c2, e};
+                            *reinterpret_cast<f32x4*>(dst + d0 * 4) = v;
+                        } else if constexpr (__is_same(OutT, __bf16)) {
+                            u32x2 v = {pack_bf16(a, b), pack_bf16(c2, e)};
+                            *reinterpret_cast<u32x2*>(dst + d0 * 2) = v;
+                        } else {
+                            u32x2 v = {pack_f16(a, b), pack_f16(c2, e)};
+                            *reinterpret_cast<u32x2*>(dst + d0 * 2) = v;
+                        }
+                    }
             }
+        }
     }
-    // 2-byte outputs: O^T accumulators -> this wave's private LDS region as a row-major [32 rows][D] tile
+    // 2-byte outputs: O^T accumulators -> this wave's private LDS region as a row-major [32R rows][D] tile
     // -> whole rows back out with 16-byte stores (each 16- or 8-lane group writes one full row).  The
     // direct form issues 16 eight-byte stores per lane that touch 32 rows each: ~8k cycles per workgroup,
-    // store-issue bound; this form ~3.3k.  16-byte chunk c of row r sits at chunk c ^ (r & mask), so the
-    // ds_write_b64 of 16 lanes (16 rows, same column) spread over all banks.  `region` = 32*D*2 bytes
+    // store-issue bound; this form ~3.3k.  16-byte chunk c of row q sits at chunk c ^ (q & mask), so the
+    // ds_write_b64 of 16 lanes (16 rows, same column) spread over all banks.  `region` = 32*R*D*2 bytes
     // private to this wave; the caller guarantees the K/V ring is dead.
     template <typename OutT>
     __device__ __forceinline__ void store_o_lds(lds_ptr region, char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S,
                                                 int lane) {
         static_assert(sizeof(OutT) == 2, "LDS epilogue is for bf16 / f16 outputs");
         constexpr int ROWB = D * 2, CHUNKS = ROWB / 16;
-        const float l_tot = sum_both_halves(l);
-        store_lse(lse_head, l_tot, row0, S, lane);
-        const float inv = 1.0f / l_tot;
         const int q = lane & 31, h = lane >> 5;
+        if constexpr (C::ASM_MFMA) mfma_drain();
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int r = 0; r < R; ++r) {
+            const float l_tot = sum_both_halves(l[r]);
+            store_lse(lse_head, l_tot, r, row0 + 32 * r, S, lane);
+            const float inv = 1.0f / l_tot;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = 32 * db + 8 * g4 + 4 * h;                  // 4 consecutive d = 8 bytes
-                const float a = o[db][4 * g4 + 0] * inv, b = o[db][4 * g4 + 1] * inv;
-                const float c2 = o[db][4 * g4 + 2] * inv, e = o[db][4 * g4 + 3] * inv;
-                u32x2 v;
-                if constexpr (__is_same(OutT, __bf16)) v = u32x2{pack_bf16(a, b), pack_bf16(c2, e)};
-                else v = u32x2{pack_f16(a, b), pack_f16(c2, e)};
-                const int chunk = (d0 * 2) >> 4, half8 = (d0 * 2) & 8;
-                *reinterpret_cast<FA_LDS u32x2*>(region + q * ROWB + (((chunk ^ q) & (CHUNKS - 1)) << 4) + half8) = v;
-            }
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d0 = 32 * db + 8 * g4 + 4 * h;                  // 4 consecutive d = 8 bytes
+                    const float a = o[r][db][4 * g4 + 0] * inv, b = o[r][db][4 * g4 + 1] * inv;
+                    const float c2 = o[r][db][4 * g4 + 2] * inv, e = o[r][db][4 * g4 + 3] * inv;
+                    u32x2 v;
+                    if constexpr (__is_same(OutT, __bf16)) v = u32x2{pack_bf16(a, b), pack_bf16(c2, e)};
+                    else v = u32x2{pack_f16(a, b), pack_f16(c2, e)};
+                    const int chunk = (d0 * 2) >> 4, half8 = (d0 * 2) & 8;
+                    *reinterpret_cast<FA_LDS u32x2*>(region + (32 * r + q) * ROWB + (((chunk ^ q) & (CHUNKS - 1)) << 4) + half8) = v;
+                }
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): only this wave's own ds_writes have to land
         constexpr int ROWS_PER_INST = 64 / CHUNKS;                          // 4 (D=128) or 8 (D=64)
         const int rr = lane / CHUNKS, cc = lane % CHUNKS;
 #pragma unroll
-        for (int i = 0; i < 32 / ROWS_PER_INST; ++i) {
-            const int r = i * ROWS_PER_INST + rr;
-            const u32x4 v = *reinterpret_cast<FA_LDS const u32x4*>(region + r * ROWB + (((cc ^ r) & (CHUNKS - 1)) << 4));
-            if (row0 + r < S) *reinterpret_cast<u32x4*>(Oh + (int64_t)(row0 + r) * oS_bytes + cc * 16) = v;
+        for (int i = 0; i < 32 * R / ROWS_PER_INST; ++i) {
+            const int row = i * ROWS_PER_INST + rr;
+            const u32x4 v = *reinterpret_cast<FA_LDS const u32x4*>(region + row * ROWB + (((cc ^ row) & (CHUNKS - 1)) << 4));
+            if (row0 + row < S) *reinterpret_cast<u32x4*>(Oh + (int64_t)(row0 + row) * oS_bytes + cc * 16) = v;
         }
     }
 };

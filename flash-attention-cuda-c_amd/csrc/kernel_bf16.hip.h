@@ -4,8 +4,12 @@
 // kernels/computers.cuh:33-67 / kernels/loaders.cuh:132-156,177-201.  The reference commits a tile and
 // immediately waits for it on every cuda::pipeline (no load/compute overlap).
 //
-// One workgroup = 8 waves = 256 query rows of one (batch, head); a wave owns 32 rows; KV tiles of 64
-// keys live in a 3-slot LDS ring [K image | V image] (loaders.hip.h).  Iteration t of a wave reads
+// One workgroup = 256 query rows of one (batch, head) = 8/R waves, a wave owning R groups of 32 rows.
+// R = 1 (8 waves, two per SIMD) is what the library launches.  R = 2 (4 waves, one per SIMD with the whole
+// 512-entry register file, every K / V^T fragment read feeding two MFMAs, inline-asm MFMAs that pin Q and
+// O in AGPRs) is an experimental arm kept for tests/fa_tune: measured +2 % non-causal, -3 % causal against
+// R = 1 (profiles/r01_tune_r1q_*.log), so it is not dispatched.  KV tiles of 64 keys live in a 3-slot LDS
+// ring [K image | V image] (loaders.hip.h).  Iteration t of a wave reads
 // K(t+1) and V(t) and stages tile t+2 into slot (t+2)%3 = slot (t-1)%3, last read in iteration t-1, which
 // every wave left at the previous barrier: ONE barrier per tile.  The loop is unrolled x2 with ping-pong
 // score registers so S(t+1) never has to be copied into S(t).  What happens inside a tile: computers.hip.h.
@@ -23,9 +27,13 @@
 namespace fa {
 
 template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, bool STAMP_ = false, bool OPTIMISTIC_ = true, int NPRE_ = 4,
-          int VPRE_ = 2, int THR_ = 8>
+          int VPRE_ = 2, int THR_ = 8, int R_ = 1, bool ASM_MFMA_ = false, bool VALU_FIRST_ = true>
 struct KernelCfg {
+    static constexpr bool VALU_FIRST = VALU_FIRST_;  // phase-A slots issue their softmax slice before the MFMA
+    static constexpr bool ASM_MFMA = ASM_MFMA_;      // inline-asm MFMAs with dictated register classes (for R = 2)
     static constexpr int D = D_;
+    static constexpr int R = R_;                     // 32-row query groups per wave (1 or 2)
+    static constexpr int NWAVES = 8 / R_;            // waves per workgroup (256 query rows)
     static constexpr bool CAUSAL = CAUSAL_;
     using OutT = OutT_;
     static constexpr int ESZ = ESZ_;                 // bytes per Q/K/V element: 2 = bf16, 1 = fp8 e4m3fn
@@ -40,7 +48,7 @@ struct KernelCfg {
 // One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the
 // result has to be recomputed with max tracking (only ever true for TRACK = false).
 template <class C, bool TRACK>
-__device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& w, BufStage<C::D, C::ESZ>& st, lds_ptr smem,
+__device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& w, typename WaveCompute<C>::Stage& st, lds_ptr smem,
                                                int n_tiles, int my_tiles, int q_row0, int lane,
                                                unsigned long long (&acc)[12], bool tile0_in_flight) {
     using G = TileGeom<C::D, C::ESZ>;
@@ -54,7 +62,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
     const int vbase = v_read_base(lane);
     const float c = p.scale_log2;
     auto needs_mask = [&](int t) { return (CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > S); };
-    f32x16 sA0, sA1, sB0, sB1;
+    Scores<C::R> sA, sB;
 
     // Prologue: tile 0 (requested by the caller together with Q on the first pass) -> LDS, barrier; then
     // tile 1 is fetched while S(0) = K(0).Q^T and its row max are computed.
@@ -64,23 +72,22 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
     st.load_all(1);          // past-the-end tiles read as zeros (buffer range check)
     if constexpr (C::STAMP) tp1 = cycle_stamp();
     if (my_tiles > 0) {
-        w.qk_all(smem, kbase, sA0, sA1);
-        if (needs_mask(0)) w.mask(sA0, sA1, 0, q_row0, S, lane);
-        w.first_max(w.row_max(sA0, sA1), c);   // m = row max of tile 0 (the reference of the optimistic pass)
+        w.qk_all(smem, kbase, sA);
+        if (needs_mask(0)) w.mask(sA, 0, q_row0, S, lane);
+        w.first_max(sA, c);   // m = row max of tile 0 (the reference of the optimistic pass)
     }
     st.write_all(smem + SLOT);
     __syncthreads();
     if constexpr (C::STAMP) { tp2 = cycle_stamp(); acc[8] += tp1 - tp0; acc[9] += tp2 - tp1; }
 
     int so_cur = 0, so_nxt = SLOT, so_wr = 2 * SLOT;   // ring slot byte offsets of tiles t, t+1, t+2
-    auto step = [&](int t, f32x16& cur0, f32x16& cur1, f32x16& nxt0, f32x16& nxt1) {
+    auto step = [&](int t, Scores<C::R>& cur, Scores<C::R>& nxt) {
         unsigned long long t0 = 0, t4 = 0, t6 = 0;
         if constexpr (C::STAMP) t0 = cycle_stamp();
         if (t < my_tiles) {
             const bool has_next = t + 1 < my_tiles;
-            w.template tile_step<TRACK>(st, t + 2, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur0,
-                                        cur1, nxt0, nxt1, has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S,
-                                        lane);
+            w.template tile_step<TRACK>(st, t + 2, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
+                                        has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
         } else {
             // wave already past its causal diagonal: it still stages its share of the tile
             st.load_all(t + 2);
@@ -98,8 +105,8 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
         so_wr = tmp;
     };
     for (int t = 0; t < n_tiles; t += 2) {
-        step(t, sA0, sA1, sB0, sB1);
-        if (t + 1 < n_tiles) step(t + 1, sB0, sB1, sA0, sA1);
+        step(t, sA, sB);
+        if (t + 1 < n_tiles) step(t + 1, sB, sA);
     }
     if constexpr (TRACK) return false;
     else {
@@ -112,7 +119,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
 }
 
 template <class C>
-__global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const Params p) {
+__global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_kernel(const Params p) {
     constexpr int D = C::D, ESZ = C::ESZ;
     constexpr bool CAUSAL = C::CAUSAL;
     using OutT = typename C::OutT;
@@ -136,15 +143,16 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const Params p) {
     float* lse_head = p.lse ? p.lse + (int64_t)g * S : nullptr;
     const int64_t qSb = p.qS * ESZ, kSb = p.kS * ESZ, vSb = p.vS * ESZ, oSb = p.oS * (int64_t)sizeof(OutT);
 
-    const int q_row0 = qb * QBLK + wave * 32;       // first query row of this wave
+    constexpr int WROWS = 32 * C::R;                // query rows per wave
+    const int q_row0 = qb * QBLK + wave * WROWS;    // first query row of this wave
     const int q_end = min(S, (qb + 1) * QBLK);      // one past the last query row of the block
     const int n_tiles = CAUSAL ? (q_end + KVBLK - 1) / KVBLK : (S + KVBLK - 1) / KVBLK;
-    // tiles this wave computes: all (non-causal) or up to its own diagonal (causal)
+    // tiles this wave computes: all (non-causal) or up to the diagonal of its last row (causal)
     const bool wave_live = q_row0 < S;
-    const int my_tiles = !wave_live ? 0 : (CAUSAL ? min(n_tiles, (q_row0 + 31) / KVBLK + 1) : n_tiles);
+    const int my_tiles = !wave_live ? 0 : (CAUSAL ? min(n_tiles, (q_row0 + WROWS - 1) / KVBLK + 1) : n_tiles);
 
     WaveCompute<C> w;
-    BufStage<D, ESZ> st;
+    typename WaveCompute<C>::Stage st;
     st.init(Kh, Vh, kSb, vSb, S, wave, lane);
     st.load_all(0);                                 // tile 0 and Q travel together (one HBM round trip)
     w.load_q(Qh, qSb, q_row0, S, lane);
@@ -163,8 +171,8 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const Params p) {
     if constexpr (C::STAMP) t_ep0 = cycle_stamp();
     if constexpr (sizeof(OutT) == 2) {
         // every pass ends behind a workgroup barrier, so no wave still reads the K/V ring: reuse it
-        static_assert(8 * 32 * D * 2 <= C::LDS_BYTES, "epilogue regions must fit the ring");
-        if (wave_live) w.template store_o_lds<OutT>(smem + wave * (32 * D * 2), Oh, lse_head, oSb, q_row0, S, lane);
+        static_assert(256 * D * 2 <= C::LDS_BYTES, "epilogue regions must fit the ring");
+        if (wave_live) w.template store_o_lds<OutT>(smem + wave * (WROWS * D * 2), Oh, lse_head, oSb, q_row0, S, lane);
     } else {
         if (wave_live) w.template store_o<OutT>(Oh, lse_head, oSb, q_row0, S, lane);
     }
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void fwd_mfma_kernel(const Params p) {
         if (lane == 0 && p.dbg) {
 #pragma unroll
             for (int k = 0; k < 11; ++k) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + k] = acc[k];
-            p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 11] = 1;
+            p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 11] = 1;   // (rows of waves that do not exist stay 0)
         }
     }
 }

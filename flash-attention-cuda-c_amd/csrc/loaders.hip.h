@@ -83,21 +83,26 @@ __device__ __forceinline__ int v_read_base(int lane) {
     return 256 * h + 64 * q + 32 * g + 8 * p;
 }
 
-// K/V tile staging.  One wave-instruction = 8 keys x 128 bytes; wave w owns keys 8w..8w+7 of every tile.
-//   K lanes: key 8w + (l&7),                    16-byte chunk (l>>3)          [+8 for the second 128-byte half]
-//   V lanes: key 8w + 2*((l>>3)&3) + ((l>>2)&1), 16-byte chunk 4*(l>>5)+(l&3) [+8 ...]
+// K/V tile staging.  One wave-instruction = 8 keys x 128 bytes.  A 64-key tile is 8 key groups x
+// (ROWB/128) column halves; with NWAVES waves each wave owns GPW = 8/NWAVES consecutive key groups.
+//   K lanes: key 8g + (l&7),                    16-byte chunk (l>>3)          [+8 for the second 128-byte half]
+//   V lanes: key 8g + 2*((l>>3)&3) + ((l>>2)&1), 16-byte chunk 4*(l>>5)+(l&3) [+8 ...]
 // chosen so that each 8-lane ds_write_b128 group writes 128 contiguous LDS bytes in the respective image.
-template <int D, int ESZ>
+template <int D, int ESZ, int NWAVES = 8>
 struct BufStage {
     using G = TileGeom<D, ESZ>;
-    static constexpr int LOADS = G::LOADS;                       // per tensor
+    static constexpr int HALVES = G::ROWB / 128;                 // 128-byte halves of a row
+    static constexpr int GPW = 8 / NWAVES;                       // key groups per wave
+    static constexpr int LOADS = HALVES * GPW;                   // 16-byte loads per thread per tensor per tile
     static constexpr int NL = 2 * LOADS;                         // loads per thread per tile
     static constexpr int VW = ESZ == 1 ? 2 : 1;                  // ds_write_b128 per V load (fp8 widens to bf16)
     static constexpr int NW = LOADS + LOADS * VW;                // LDS writes per thread per tile
+    static_assert(8 % NWAVES == 0, "NWAVES must divide the 8 key groups of a tile");
     __amdgpu_buffer_rsrc_t krsrc, vrsrc;
     int koff, voff;        // per-lane byte offset of load 0 inside a tile (constant)
     int klds, vlds;        // per-lane LDS byte offset of write 0 inside the K / V image
     int ktile, vtile;      // bytes per 64-key tile step (scalar)
+    int kgrp, vgrp;        // bytes per 8-key group step in global memory (scalar)
     u32x4 r[NL];           // staged data: [0,LOADS) = K, [LOADS,NL) = V
 
     __device__ __forceinline__ void init(const char* Kh, const char* Vh, int64_t kS_bytes, int64_t vS_bytes, int S,
@@ -107,34 +112,42 @@ struct BufStage {
         vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (int)(S * vS_bytes), 0x00020000);
         ktile = (int)(64 * kS_bytes);
         vtile = (int)(64 * vS_bytes);
-        const int kk = 8 * wave + (lane & 7), kc = lane >> 3;
-        const int vk = 8 * wave + 2 * ((lane >> 3) & 3) + ((lane >> 2) & 1), vc = 4 * (lane >> 5) + (lane & 3);
+        kgrp = (int)(8 * kS_bytes);
+        vgrp = (int)(8 * vS_bytes);
+        const int g0 = wave * GPW;
+        const int kk = 8 * g0 + (lane & 7), kc = lane >> 3;
+        const int vk = 8 * g0 + 2 * ((lane >> 3) & 3) + ((lane >> 2) & 1), vc = 4 * (lane >> 5) + (lane & 3);
         koff = kk * (int)kS_bytes + kc * 16;
         voff = vk * (int)vS_bytes + vc * 16;
         klds = G::k_lds_off(kk, kc);
         vlds = G::v_lds_off(vk, ESZ == 1 ? 2 * vc : vc);   // fp8: 16 input bytes = bf16 chunks 2c, 2c+1
     }
-    // load #N of tile t (N < LOADS: K half N, else V half N-LOADS).  The tile offset goes into the VGPR
-    // offset (one v_add with a scalar operand) so the hardware range check certainly covers it.
+    // load #N of tile t (N < LOADS: K, else V): key group g0 + n/HALVES, 128-byte half n%HALVES.  The tile
+    // offset goes into the VGPR offset (v_add with scalar operands) so the hardware range check covers it.
     template <int N>
     __device__ __forceinline__ void load(int t) {
+        constexpr int n = N < LOADS ? N : N - LOADS;
+        constexpr int gi = n / HALVES, hf = n % HALVES;
         if constexpr (N < LOADS)
-            r[N] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krsrc, koff + t * ktile + N * 128, 0, 0));
+            r[N] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krsrc, koff + t * ktile + gi * kgrp + hf * 128, 0, 0));
         else
-            r[N] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, voff + t * vtile + (N - LOADS) * 128, 0, 0));
+            r[N] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, voff + t * vtile + gi * vgrp + hf * 128, 0, 0));
     }
-    // LDS write #N (N < LOADS: K half N; then the V writes).  +8 K chunks = +8 KiB; +8 bf16 V chunks = +1 KiB.
+    // LDS write #N: the K writes, then the V writes.  K image: +8 keys = +128 B, +8 chunks = +8 KiB.
+    // V image: +8 keys = +DB*512 B, +8 bf16 chunks = +1 KiB.
     template <int N>
     __device__ __forceinline__ void write(lds_ptr slot_base) const {
         if constexpr (N < LOADS) {
-            lds_write_b128(slot_base, klds + N * 8192, r[N]);
+            constexpr int gi = N / HALVES, hf = N % HALVES;
+            lds_write_b128(slot_base, klds + gi * 128 + hf * 8192, r[N]);
         } else if constexpr (ESZ == 2) {
-            lds_write_b128(slot_base + G::K_TILE, vlds + (N - LOADS) * 1024, r[N]);
+            constexpr int n = N - LOADS, gi = n / HALVES, hf = n % HALVES;
+            lds_write_b128(slot_base + G::K_TILE, vlds + gi * (G::DB * 512) + hf * 1024, r[N]);
         } else {
-            // fp8 V: 16 e4m3fn bytes -> 16 bf16 (exact), written as two adjacent 16-byte chunks
-            constexpr int W = N - LOADS;   // 0: low 8 bytes, 1: high 8 bytes of the single V load
-            const u32x4 src = r[LOADS];
-            lds_write_b128(slot_base + G::K_TILE, vlds + W * 16, fp8x8_to_bf16x8(src[2 * W], src[2 * W + 1]));
+            // fp8 V (ROWB = 128, one half): 16 e4m3fn bytes -> 16 bf16 (exact), two adjacent 16-byte chunks
+            constexpr int n = (N - LOADS) / 2, W = (N - LOADS) % 2;   // load n of this tensor, low / high 8 bytes
+            const u32x4 src = r[LOADS + n];
+            lds_write_b128(slot_base + G::K_TILE, vlds + n * (G::DB * 512) + W * 16, fp8x8_to_bf16x8(src[2 * W], src[2 * W + 1]));
         }
     }
     template <int N = 0> __device__ __forceinline__ void load_all(int t) { if constexpr (N < NL) { load<N>(t); load_all<N + 1>(t); } }

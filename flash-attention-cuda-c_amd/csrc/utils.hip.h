@@ -43,6 +43,30 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_fp8(uint64_t a, uint64_t b, f32x
     return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8((long)a, (long)b, c, 0, 0, 0);
 }
 
+// ---- MFMAs with dictated register classes (R = 2 kernels, one wave per SIMD, 512 registers) ------
+// hipcc's own allocation keeps the score accumulators in AGPRs and shuttles them to VGPRs for the
+// softmax (320 v_accvgpr copies per tile).  These inline-asm forms pin: scores + K/V^T/P fragments in
+// VGPRs ("v"), Q fragments and the O accumulators in AGPRs ("a").  hipcc does not see an MFMA inside
+// asm, so it pads no hazards: callers keep MFMA results away from non-MFMA readers (see computers.hip.h)
+// and PAD (s_nop 1) covers a B operand written by a VALU instruction in the previous two issue slots.
+template <bool FIRST>   // FIRST: C = 0 (start of an accumulation chain)
+__device__ __forceinline__ void mfma_qk_asm(f32x16& acc, const u32x4& kfrag, const u32x4& qfrag) {
+    if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(kfrag), "a"(qfrag));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(kfrag), "a"(qfrag));
+}
+template <bool FIRST>
+__device__ __forceinline__ void mfma_qk_fp8_asm(f32x16& acc, uint64_t a, uint64_t b) {
+    if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_fp8_fp8 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b));
+    else asm volatile("v_mfma_f32_32x32x16_fp8_fp8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+}
+template <bool PAD>
+__device__ __forceinline__ void mfma_pv_asm(f32x16& o, const bf16x8& vfrag, const bf16x8& pfrag) {
+    if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vfrag), "v"(pfrag));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vfrag), "v"(pfrag));
+}
+// 16-pass MFMA result -> non-MFMA reader: wait out the pipeline (rare paths only: rescale, epilogue)
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
 // Row of the 32x32 accumulator tile held in register `reg` of lane half `h`.
 __host__ __device__ constexpr int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 

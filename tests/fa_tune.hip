@@ -57,7 +57,7 @@ static void launch_cfg(const Params& p, int grid) {
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((fwd_mfma_kernel<K>), dim3(grid), dim3(512), K::LDS_BYTES, nullptr, p);
+    hipLaunchKernelGGL((fwd_mfma_kernel<K>), dim3(grid), dim3(64 * K::NWAVES), K::LDS_BYTES, nullptr, p);
 }
 
 // KernelCfg<D, CAUSAL, OutT, ESZ, STAMP, OPTIMISTIC, NPRE, VPRE, THR>
@@ -65,6 +65,8 @@ template <int D, bool CAUSAL>
 static std::vector<Variant> make_variants() {
     std::vector<Variant> v;
     v.push_back({"production (optimistic, npre4 vpre2)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2>>});
+    v.push_back({"MFMA-first slots (old order)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, false>>});
+    v.push_back({"R=2 asm npre4 vpre2 (experimental)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 2, true, true>>});
     v.push_back({"tracked only", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, false, 4, 2>>});
     v.push_back({"optimistic npre6 vpre3", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 6, 3>>});
     v.push_back({"production STAMP", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, true, true, 4, 2>>});
