@@ -12,6 +12,7 @@
 #include "../../include/flash_attention.h"
 #include "../helpers.hpp"
 #include "kernel_bf16.hip.h"
+#include "kernel_f32.hip.h"
 #include "generic.hip.h"
 
 namespace fa {
@@ -71,7 +72,17 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
     (void)causal; (void)o_dtype;
     const bool mfma_bf16 = dtype == FA_DTYPE_BF16 && (d == 64 || d == 128) && scale > 0.f;
     const bool mfma_fp8 = dtype == FA_DTYPE_FP8_E4M3 && d == 128 && scale > 0.f;
-    if (mfma_bf16 || mfma_fp8) {
+    const bool mfma_f32 = dtype == FA_DTYPE_F32 && (d == 64 || d == 128) && scale > 0.f;
+    if (mfma_f32) {
+        plan->kernel_id = 3;
+        plan->q_block_rows = calculateSizeBlockQ(d, dtype);
+        plan->kv_block_rows = calculateSizeBlockKV(d, dtype);
+        plan->threads = 256;
+        plan->lds_bytes = d == 128 ? F32Cfg<128, false, float>::LDS_BYTES : F32Cfg<64, false, float>::LDS_BYTES;
+        const int nQ = getNumCta(S, plan->q_block_rows);
+        const int64_t units = (int64_t)B * H * nQ;
+        plan->grid = (int)(8 * ((units + 7) / 8));
+    } else if (mfma_bf16 || mfma_fp8) {
         plan->kernel_id = mfma_fp8 ? 2 : 1;
         plan->q_block_rows = calculateSizeBlockQ(d, dtype);
         plan->kv_block_rows = calculateSizeBlockKV(d, dtype);
@@ -110,6 +121,22 @@ static hipError_t launch_mfma_out(const Params& p, const fa_launch_plan& plan, i
     if (o_dtype == FA_DTYPE_F32) return launch_mfma<KernelCfg<D, CAUSAL, float, ESZ>>(p, plan, st);
     if (o_dtype == FA_DTYPE_BF16) return launch_mfma<KernelCfg<D, CAUSAL, __bf16, ESZ>>(p, plan, st);
     return launch_mfma<KernelCfg<D, CAUSAL, _Float16, ESZ>>(p, plan, st);
+}
+
+template <class Cfg>
+static hipError_t launch_f32(const Params& p, const fa_launch_plan& plan, hipStream_t st) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)fwd_f32_mfma_kernel<Cfg>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((fwd_f32_mfma_kernel<Cfg>), dim3(plan.grid), dim3(plan.threads), Cfg::LDS_BYTES, st, p);
+    return hipGetLastError();
+}
+
+template <int D, bool CAUSAL>
+static hipError_t launch_f32_out(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
+    if (o_dtype == FA_DTYPE_F32) return launch_f32<F32Cfg<D, CAUSAL, float>>(p, plan, st);
+    if (o_dtype == FA_DTYPE_BF16) return launch_f32<F32Cfg<D, CAUSAL, __bf16>>(p, plan, st);
+    return launch_f32<F32Cfg<D, CAUSAL, _Float16>>(p, plan, st);
 }
 
 template <typename InT, typename OutT>
@@ -154,7 +181,10 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
     p.dbg = nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
-    if (plan.kernel_id == 2) {
+    if (plan.kernel_id == 3) {
+        if (d == 128) e = causal ? launch_f32_out<128, true>(p, plan, o_dtype, st) : launch_f32_out<128, false>(p, plan, o_dtype, st);
+        else          e = causal ? launch_f32_out<64, true>(p, plan, o_dtype, st) : launch_f32_out<64, false>(p, plan, o_dtype, st);
+    } else if (plan.kernel_id == 2) {
         e = causal ? launch_mfma_out<128, true, 1>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 1>(p, plan, o_dtype, st);
     } else if (plan.kernel_id == 1) {
         if (d == 128) e = causal ? launch_mfma_out<128, true, 2>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 2>(p, plan, o_dtype, st);

@@ -12,6 +12,8 @@
 //      staging 8*d/64 -- about 200 at d = 128.
 //   Bc (keys / tile): 64.  Two 32-key score tiles per wave; K + V tile = 32 KiB at d = 128,
 //      double-buffered = 64 KiB of the CU's 160 KiB LDS.
+//   exact-fp32 MFMA kernel (fp32 inputs, d in {64,128}): Br = 128 (4 waves x 32 rows, 2 workgroups per CU),
+//      Bc = 32 (K image 16 KiB + transposed V image 18 KiB per buffer, two buffers).
 //   generic exact-fp32 kernel: Br = Bc = 32 (VALU path, any d <= 256, any seqLen).
 #pragma once
 
@@ -20,6 +22,7 @@
 inline int calculateSizeBlockQ(int d_head, int dtype) {
     if (dtype == FA_DTYPE_BF16 && (d_head == 64 || d_head == 128)) return 256;
     if (dtype == FA_DTYPE_FP8_E4M3 && d_head == 128) return 256;
+    if (dtype == FA_DTYPE_F32 && (d_head == 64 || d_head == 128)) return 128;   // exact-fp32 MFMA kernel: 4 waves x 32 rows
     return 32;
 }
 

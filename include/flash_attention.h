@@ -77,7 +77,8 @@ enum {
  *   stream      hipStream_t (passed as void* so this header needs no HIP include); NULL = the
  *               default stream
  *
- * Supported: f32 inputs, any dHead <= 256, any seqLen (exact-fp32 path);
+ * Supported: f32 inputs, any dHead <= 256, any seqLen (exact fp32: dHead in {64,128} on the f32-input
+ *            MFMA, everything else on the generic VALU kernel);
  *            bf16 inputs, dHead in {64,128} on the MFMA path (any seqLen >= 1), other dHead
  *            <= 256 on the generic path; fp8 e4m3fn inputs, dHead = 128 (QK^T on the fp8 MFMA).
  *            One head's K/V extent (seqLen x row stride) must stay below 2^31 bytes on the MFMA paths.
@@ -128,7 +129,7 @@ typedef struct fa_launch_plan {
     int threads;         /* threads per workgroup                  (tests/main.cu:52)  */
     int grid;            /* number of workgroups                   (helpers.hpp:33-36) */
     int lds_bytes;       /* dynamic LDS per workgroup              (tests/main.cu:55)  */
-    int kernel_id;       /* which internal kernel: 0 generic-f32 VALU, 1 bf16 MFMA, 2 fp8 MFMA */
+    int kernel_id;       /* which internal kernel: 0 generic fp32 VALU, 1 bf16 MFMA, 2 fp8 MFMA, 3 exact-fp32 MFMA */
 } fa_launch_plan;
 
 int flash_attention_plan(int batchSize, int numHeads, int seqLen, int dHead, bool is_causal,

@@ -205,6 +205,10 @@ int main(int argc, char** argv) {
         cases.push_back({1, 1, 128, 64, 0, 0, 0, 0});   // BASELINE cfg0 shape
         cases.push_back({2, 3, 77, 40, 1, 0, 0, 0});
         cases.push_back({1, 2, 300, 256, 0, 0, 0, 0});
+        // exact-fp32 MFMA kernel (fp32 inputs, d in {64,128})
+        cases.push_back({1, 2, 128, 128, 0, 0, 0, 0});
+        cases.push_back({2, 2, 1000, 128, 1, 0, 0, 0});
+        cases.push_back({1, 2, 1024, 64, 1, 0, 0, 2});
         // bf16 MFMA path
         cases.push_back({1, 1, 64, 128, 0, 1, 0, 0});
         cases.push_back({1, 1, 64, 128, 0, 1, 0, 1});
@@ -227,6 +231,7 @@ int main(int argc, char** argv) {
             cases.push_back({4, 8, 2048, 64, 0, 1, 0, 0});    // BASELINE cfg1
             cases.push_back({8, 16, 4096, 128, 1, 1, 0, 0});  // BASELINE cfg2 (sampled heads)
             cases.push_back({8, 16, 4096, 128, 0, 1, 0, 0});
+            cases.push_back({2, 8, 4096, 128, 0, 0, 0, 0});   // fp32 (the reference's own dtype) at the headline S, d
             cases.push_back({1, 16, 16384, 128, 0, 2, 1, 0}); // BASELINE cfg3: fp8 e4m3, S=16384, d=128 (B=1, H=16 chosen)
         }
     }

@@ -71,6 +71,8 @@ def test_strided_validation():
     (8, 16, 4096, 128, True, fa.FA_DTYPE_BF16, 1, 256, 64),    # BASELINE cfg2
     (4, 8, 2048, 64, False, fa.FA_DTYPE_BF16, 1, 256, 64),     # BASELINE cfg1
     (1, 1, 16, 16, False, fa.FA_DTYPE_F32, 0, 32, 32),         # tests/main.cu:107
+    (1, 1, 128, 64, False, fa.FA_DTYPE_F32, 3, 128, 32),       # BASELINE cfg0's shape, exact-fp32 MFMA kernel
+    (2, 4, 4096, 128, True, fa.FA_DTYPE_F32, 3, 128, 32),
     (1, 2, 200, 80, True, fa.FA_DTYPE_BF16, 0, 32, 32),        # bf16, d not in {64,128}
     (1, 16, 16384, 128, False, fa.FA_DTYPE_FP8_E4M3, 2, 256, 64),  # BASELINE cfg3 (fp8 e4m3fn)
 ])

@@ -106,7 +106,10 @@ def test_golden_layout_bf16_two_heads(golden):
 
 # ------------------------------------------------------------------ random parity vs the oracle
 FP32_CASES = [(1, 1, 128, 64, False), (2, 3, 77, 40, True), (1, 2, 300, 256, False), (1, 1, 1, 16, True),
-              (1, 2, 33, 8, True), (3, 1, 65, 100, False)]
+              (1, 2, 33, 8, True), (3, 1, 65, 100, False),
+              # exact-fp32 MFMA kernel (d in {64,128})
+              (1, 2, 128, 128, False), (2, 2, 1000, 128, True), (1, 3, 333, 64, True), (1, 1, 1, 128, True),
+              (1, 2, 2048, 64, False), (1, 1, 31, 128, False)]
 
 
 @pytest.mark.parametrize("B,H,S,d,causal", FP32_CASES)
@@ -238,6 +241,27 @@ def test_lse_output(dtype, d, S, causal):
         np.testing.assert_allclose(lse.cpu().numpy(), ref, rtol=2e-5, atol=2e-4 * mul * mul)
         refO = oracle.attention(Qm.float().numpy(), Km.float().numpy(), V.float().numpy(), causal=causal)
         check(O.cpu().numpy(), refO, 1.6e-2, 1.6e-2)
+
+
+def test_fp32_mfma_path_spike_and_outputs():
+    """fp32 inputs, d = 128: the f32-input MFMA kernel keeps fp32 end to end.  Forced rescale (spike), large
+    score range, bf16 output and LSE."""
+    B, H, S, d = 1, 2, 768, 128
+    Q, K, V = (randn((B, H, S, d), s, torch.float32) for s in (90, 91, 92))
+    K[:, :, 500] = 6.0 * Q[:, :, 3]
+    K[:, :, 40] = 12.0 * Q[:, :, 700]
+    for causal in (False, True):
+        ref = oracle.attention(Q.numpy(), K.numpy(), V.numpy(), causal=causal)
+        O, lse = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, return_lse=True)
+        torch.cuda.synchronize()
+        check(O.cpu().numpy(), ref, 2e-5, 1e-4)
+        np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(Q.numpy(), K.numpy(), causal=causal), rtol=2e-6, atol=2e-4)
+        check(run_gpu(Q, K, V, causal, out_dtype=torch.bfloat16), ref, 8e-3, 8e-3)
+    # scores 36x larger (sigma 36, spikes in the thousands): an fp32 score carries ~|s|*2^-24*sqrt(d) of rounding
+    # noise which exp() turns into relative error, so the bound is looser here -- the same allowance the
+    # peaky golden fixture F6 gets in test_oracle.py
+    Q6, K6 = Q * 6, K * 6
+    check(run_gpu(Q6, K6, V, False), oracle.attention(Q6.numpy(), K6.numpy(), V.numpy()), 2e-4, 2e-4)
 
 
 def test_heads_are_independent():
