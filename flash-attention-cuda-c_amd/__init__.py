@@ -27,7 +27,7 @@ LIB_PATH = os.path.join(_HERE, "libflash_attention.so")
 FA_DTYPE_F32, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3, FA_DTYPE_F16 = 0, 1, 2, 3
 
 # every symbol include/flash_attention.h declares
-EXPORTS = ("flash_attention", "flash_attention_strided", "flash_attention_lse", "flash_attention_plan",
+EXPORTS = ("flash_attention", "flash_attention_strided", "flash_attention_lse", "flash_attention_cross", "flash_attention_weights", "flash_attention_plan",
            "flash_attention_error_string", "flash_attention_version")
 
 
@@ -66,6 +66,10 @@ def lib() -> ctypes.CDLL:
         L.flash_attention_strided.restype = i
         L.flash_attention_lse.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, f, b, i, i, vp]
         L.flash_attention_lse.restype = i
+        L.flash_attention_cross.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, f, b, i, i, sp, sp, sp, sp, vp]
+        L.flash_attention_cross.restype = i
+        L.flash_attention_weights.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, b, i, sp, sp, vp]
+        L.flash_attention_weights.restype = i
         L.flash_attention_plan.argtypes = [i, i, i, i, b, i, i, ctypes.POINTER(FaLaunchPlan)]
         L.flash_attention_plan.restype = i
         L.flash_attention_error_string.argtypes = [i]
@@ -124,22 +128,25 @@ def plan(batchSize, numHeads, seqLen, dHead, is_causal=False, dtype=FA_DTYPE_BF1
 
 
 def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None, stream=None, return_lse=False):
-    """O = softmax(scale * Q K^T [+ causal mask]) V on dense [B, H, S, d] device tensors.
+    """O = softmax(scale * Q K^T [+ causal mask]) V on [B, H, S, d] device tensors.
 
     Argument order and meaning follow the reference kernel (Q, K, V, O, batchSize, numHeads,
     seqLen, scale, is_causal -- kernels/FlashAttention.cuh:59-63); batchSize/numHeads/seqLen/dHead
-    are read from Q.shape, ``scale`` defaults to 1/sqrt(d) (tests/main.cu:27).  Asynchronous on
-    ``stream`` (default: torch's current stream).  Returns O, or ``(O, LSE)`` with ``return_lse=True``
-    (LSE: fp32 [B, H, S], natural-log sum of exp(scale * scores) over the visible keys; dense tensors only).
+    are read from Q.shape, ``scale`` defaults to 1/sqrt(d) (tests/main.cu:27).  K and V may hold a
+    different number of rows than Q (``[B, H, Sk, d]``: the seqLenQ / seqLenK of the reference's first
+    API, kernels/FlashAttention.cuh:23); the causal mask stays ``k > q`` on absolute indices.
+    Asynchronous on ``stream`` (default: torch's current stream).  Returns O, or ``(O, LSE)`` with
+    ``return_lse=True`` (LSE: fp32 [B, H, S], natural-log sum of exp(scale * scores) over the visible keys).
     """
     import torch
     if not (Q.is_cuda and K.is_cuda and V.is_cuda):
         raise RuntimeError("flash_attention needs device tensors (no CPU fallback)")
-    if Q.dim() != 4 or Q.shape != K.shape or Q.shape != V.shape:
-        raise ValueError("Q, K, V must be [B, H, S, d] tensors of one shape")
+    if Q.dim() != 4 or K.dim() != 4 or K.shape != V.shape or Q.shape[:2] != K.shape[:2] or Q.shape[3] != K.shape[3]:
+        raise ValueError("Q must be [B, H, S, d] and K, V [B, H, Sk, d]")
     if not (Q.dtype == K.dtype == V.dtype):
         raise TypeError("Q, K, V must share a dtype")
     B, H, S, d = Q.shape
+    Sk = K.shape[2]
     if scale is None:
         scale = 1.0 / float(d) ** 0.5
     if O is None:
@@ -147,45 +154,61 @@ def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None
     elif O.shape != Q.shape or not O.is_cuda:
         raise ValueError("O must be a device tensor shaped like Q")
     dense = all(t.is_contiguous() for t in (Q, K, V, O))
-    lse = None
-    if return_lse:
-        if not dense:
-            raise ValueError("return_lse needs dense [B, H, S, d] tensors")
-        lse = torch.empty((B, H, S), dtype=torch.float32, device=Q.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=Q.device) if return_lse else None
+    common = (float(scale), bool(is_causal), _dtype_code(Q.dtype), _dtype_code(O.dtype))
+    ptrs = (Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr())
     with torch.cuda.device(Q.device):
-        if lse is not None:
-            rc = lib().flash_attention_lse(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), lse.data_ptr(), B, H, S,
-                                           d, float(scale), bool(is_causal), _dtype_code(Q.dtype), _dtype_code(O.dtype),
-                                           _stream_ptr(stream))
-        elif dense:
-            rc = lib().flash_attention(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, S, d,
-                                       float(scale), bool(is_causal), _dtype_code(Q.dtype), _dtype_code(O.dtype),
-                                       _stream_ptr(stream))
+        if dense and Sk == S and lse is not None:
+            rc = lib().flash_attention_lse(*ptrs, lse.data_ptr(), B, H, S, d, *common, _stream_ptr(stream))
+        elif dense and Sk == S:
+            rc = lib().flash_attention(*ptrs, B, H, S, d, *common, _stream_ptr(stream))
         else:
             st = []
             for t in (Q, K, V, O):
                 if t.stride(3) != 1:
                     raise ValueError("last dimension must be contiguous")
                 st.append(FaStrides(t.stride(0), t.stride(1), t.stride(2)))
-            rc = lib().flash_attention_strided(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, S, d,
-                                               float(scale), bool(is_causal), _dtype_code(Q.dtype),
-                                               _dtype_code(O.dtype), ctypes.byref(st[0]), ctypes.byref(st[1]),
-                                               ctypes.byref(st[2]), ctypes.byref(st[3]), _stream_ptr(stream))
+            refs = [ctypes.byref(x) for x in st]
+            if Sk == S and lse is None:
+                rc = lib().flash_attention_strided(*ptrs, B, H, S, d, *common, *refs, _stream_ptr(stream))
+            else:
+                rc = lib().flash_attention_cross(*ptrs, lse.data_ptr() if lse is not None else None, B, H, S, Sk, d,
+                                                 *common, *refs, _stream_ptr(stream))
     _check(rc)
     return (O, lse) if return_lse else O
+
+
+def attention_weights(Q, K, lse, scale=None, is_causal=False, stream=None):
+    """attn[b,h,q,k] = exp(scale * <Q[q], K[k]> - lse[q]) as a dense fp32 [B, H, Sq, Sk] device tensor -- the
+    matrix check.py:20,25 returns as ``attn`` -- from the LSE of a ``flash_attention(..., return_lse=True)``
+    call.  Inspection path for small sequences (the fused kernel itself never stores it)."""
+    import torch
+    B, H, S, d = Q.shape
+    Sk = K.shape[2]
+    if scale is None:
+        scale = 1.0 / float(d) ** 0.5
+    if Q.stride(3) != 1 or K.stride(3) != 1 or not lse.is_contiguous() or lse.dtype != torch.float32:
+        raise ValueError("last dimension must be contiguous; lse must be dense fp32 [B, H, S]")
+    P = torch.empty((B, H, S, Sk), dtype=torch.float32, device=Q.device)
+    sq, sk = (FaStrides(t.stride(0), t.stride(1), t.stride(2)) for t in (Q, K))
+    with torch.cuda.device(Q.device):
+        rc = lib().flash_attention_weights(Q.data_ptr(), K.data_ptr(), lse.data_ptr(), P.data_ptr(), B, H, S, Sk, d,
+                                           float(scale), bool(is_causal), _dtype_code(Q.dtype), ctypes.byref(sq),
+                                           ctypes.byref(sk), _stream_ptr(stream))
+    _check(rc)
+    return P
 
 
 def multi_head_attention(Q, K, V, num_heads, is_causal=False, return_attn=False, out_dtype=None):
     """Drop-in for the reference's ``check.py:multi_head_attention(Q, K, V, num_heads)``.
 
     Q, K, V: (batch, seq_len, d_model) device tensors.  Returns ``(output, attn)`` like check.py:25,
-    with output (batch, seq_len, d_model); the (B,H,S,S) attention matrix is never materialised by
-    the fused kernel, so ``attn`` is None (``return_attn=True`` raises -- SURVEY.md section 8f row 4).
+    with output (batch, seq_len, d_model).  The fused kernel never materialises the (B,H,S,S) attention
+    matrix, so ``attn`` is None unless ``return_attn=True``, which rebuilds it (fp32) from the kernel's
+    log-sum-exp with a second small kernel -- meant for the small shapes check.py's demo prints.
     The head split / merge of check.py:14-16,24 is done with strides: no transpose copies.
     """
     import torch
-    if return_attn:
-        raise NotImplementedError("the fused forward kernel does not materialise attn (B,H,S,S)")
     if Q.dim() != 3:
         raise ValueError("Q, K, V must be (batch, seq_len, d_model)")
     B, S, dm = Q.shape
@@ -194,5 +217,9 @@ def multi_head_attention(Q, K, V, num_heads, is_causal=False, return_attn=False,
     dk = dm // num_heads                                                 # check.py:11
     out = torch.empty((B, S, dm), device=Q.device, dtype=out_dtype or _default_out_dtype(Q.dtype))
     view = lambda t: t.view(B, S, num_heads, dk).transpose(1, 2)         # check.py:14-16 (views only)
-    flash_attention(view(Q), view(K), view(V), view(out), scale=1.0 / float(dk) ** 0.5, is_causal=is_causal)
-    return out, None
+    scale = 1.0 / float(dk) ** 0.5                                       # check.py:19
+    if not return_attn:
+        flash_attention(view(Q), view(K), view(V), view(out), scale=scale, is_causal=is_causal)
+        return out, None
+    _, lse = flash_attention(view(Q), view(K), view(V), view(out), scale=scale, is_causal=is_causal, return_lse=True)
+    return out, attention_weights(view(Q), view(K), lse, scale=scale, is_causal=is_causal)

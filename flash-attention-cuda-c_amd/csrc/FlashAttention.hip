@@ -14,6 +14,7 @@
 #include "kernel_bf16.hip.h"
 #include "kernel_f32.hip.h"
 #include "generic.hip.h"
+#include "weights.hip.h"
 
 namespace fa {
 
@@ -23,15 +24,16 @@ namespace fa {
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static int fill_params(Params& p, const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H,
-                       int S, int d, float scale, const fa_strides* sQ, const fa_strides* sK,
+                       int S, int Sk, int d, float scale, const fa_strides* sQ, const fa_strides* sK,
                        const fa_strides* sV, const fa_strides* sO) {
     p.Q = Q; p.K = K; p.V = V; p.O = O; p.lse = lse;
-    const int64_t dS = d, dH = (int64_t)S * d, dB = (int64_t)H * S * d;
+    const int64_t dS = d, dH = (int64_t)S * d, dB = (int64_t)H * S * d;      // dense Q / O
+    const int64_t kH = (int64_t)Sk * d, kB = (int64_t)H * Sk * d;            // dense K / V
     p.qB = sQ ? sQ->strideB : dB; p.qH = sQ ? sQ->strideH : dH; p.qS = sQ ? sQ->strideS : dS;
-    p.kB = sK ? sK->strideB : dB; p.kH = sK ? sK->strideH : dH; p.kS = sK ? sK->strideS : dS;
-    p.vB = sV ? sV->strideB : dB; p.vH = sV ? sV->strideH : dH; p.vS = sV ? sV->strideS : dS;
+    p.kB = sK ? sK->strideB : kB; p.kH = sK ? sK->strideH : kH; p.kS = sK ? sK->strideS : dS;
+    p.vB = sV ? sV->strideB : kB; p.vH = sV ? sV->strideH : kH; p.vS = sV ? sV->strideS : dS;
     p.oB = sO ? sO->strideB : dB; p.oH = sO ? sO->strideH : dH; p.oS = sO ? sO->strideS : dS;
-    p.B = B; p.H = H; p.S = S;
+    p.B = B; p.H = H; p.S = S; p.Sk = Sk;
     p.scale = scale;
     p.scale_log2 = scale * 1.4426950408889634f;
     return FA_OK;
@@ -156,11 +158,12 @@ static hipError_t launch_generic(const Params& p, const fa_launch_plan& plan, in
     return launch_generic_io<InT, _Float16>(p, plan, d, causal, st);
 }
 
-static int run(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int S, int d,
+static int run(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int S, int Sk, int d,
                float scale, bool causal, int dtype, int o_dtype, const fa_strides* sQ,
                const fa_strides* sK, const fa_strides* sV, const fa_strides* sO, void* stream) {
     int rc = validate(Q, K, V, O, B, H, S, d, scale, dtype, o_dtype);
     if (rc != FA_OK) return rc;
+    if (Sk <= 0 || Sk > (1 << 24)) return FA_ERR_BAD_SHAPE;
     if (lse && !aligned16(lse)) return FA_ERR_MISALIGNED;
     const int esz = elem_size(dtype), osz = elem_size(o_dtype);
     if (!strides_ok(sQ, esz, d) || !strides_ok(sK, esz, d) || !strides_ok(sV, esz, d) || !strides_ok(sO, osz, d))
@@ -171,10 +174,10 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
         // K/V are fetched through buffer descriptors with 32-bit byte offsets: one head's extent
         // (seqLen x row stride) must stay below 2^31 bytes (two prefetch tiles of slack included)
         const int64_t ks = sK ? sK->strideS : d, vs = sV ? sV->strideS : d;
-        if (((int64_t)S + 192) * ks * esz >= (1ll << 31) || ((int64_t)S + 192) * vs * esz >= (1ll << 31)) return FA_ERR_BAD_SHAPE;
+        if (((int64_t)Sk + 192) * ks * esz >= (1ll << 31) || ((int64_t)Sk + 192) * vs * esz >= (1ll << 31)) return FA_ERR_BAD_SHAPE;
     }
     Params p;
-    fill_params(p, Q, K, V, O, lse, B, H, S, d, scale, sQ, sK, sV, sO);
+    fill_params(p, Q, K, V, O, lse, B, H, S, Sk, d, scale, sQ, sK, sV, sO);
     p.nQ = getNumCta(S, plan.q_block_rows);
     p.units = B * H * p.nQ;
     p.cpx = (p.units + 7) / 8;
@@ -204,13 +207,13 @@ extern "C" {
 int flash_attention(const void* Q, const void* K, const void* V, void* O, int batchSize, int numHeads,
                     int seqLen, int dHead, float scale, bool is_causal, int dtype, int o_dtype,
                     void* stream) {
-    return fa::run(Q, K, V, O, nullptr, batchSize, numHeads, seqLen, dHead, scale, is_causal, dtype, o_dtype,
+    return fa::run(Q, K, V, O, nullptr, batchSize, numHeads, seqLen, seqLen, dHead, scale, is_causal, dtype, o_dtype,
                    nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int flash_attention_lse(const void* Q, const void* K, const void* V, void* O, float* LSE, int batchSize, int numHeads,
                         int seqLen, int dHead, float scale, bool is_causal, int dtype, int o_dtype, void* stream) {
-    return fa::run(Q, K, V, O, LSE, batchSize, numHeads, seqLen, dHead, scale, is_causal, dtype, o_dtype,
+    return fa::run(Q, K, V, O, LSE, batchSize, numHeads, seqLen, seqLen, dHead, scale, is_causal, dtype, o_dtype,
                    nullptr, nullptr, nullptr, nullptr, stream);
 }
 
@@ -218,8 +221,47 @@ int flash_attention_strided(const void* Q, const void* K, const void* V, void* O
                             int numHeads, int seqLen, int dHead, float scale, bool is_causal, int dtype,
                             int o_dtype, const fa_strides* sQ, const fa_strides* sK,
                             const fa_strides* sV, const fa_strides* sO, void* stream) {
-    return fa::run(Q, K, V, O, nullptr, batchSize, numHeads, seqLen, dHead, scale, is_causal, dtype, o_dtype, sQ,
+    return fa::run(Q, K, V, O, nullptr, batchSize, numHeads, seqLen, seqLen, dHead, scale, is_causal, dtype, o_dtype, sQ,
                    sK, sV, sO, stream);
+}
+
+int flash_attention_cross(const void* Q, const void* K, const void* V, void* O, float* LSE, int batchSize, int numHeads,
+                          int seqLenQ, int seqLenK, int dHead, float scale, bool is_causal, int dtype, int o_dtype,
+                          const fa_strides* sQ, const fa_strides* sK, const fa_strides* sV, const fa_strides* sO,
+                          void* stream) {
+    return fa::run(Q, K, V, O, LSE, batchSize, numHeads, seqLenQ, seqLenK, dHead, scale, is_causal, dtype, o_dtype, sQ,
+                   sK, sV, sO, stream);
+}
+
+int flash_attention_weights(const void* Q, const void* K, const float* LSE, float* P, int batchSize, int numHeads,
+                            int seqLenQ, int seqLenK, int dHead, float scale, bool is_causal, int dtype,
+                            const fa_strides* sQ, const fa_strides* sK, void* stream) {
+    using namespace fa;
+    if (!Q || !K || !LSE || !P) return FA_ERR_NULL_POINTER;
+    if (!aligned16(Q) || !aligned16(K) || !aligned16(LSE) || !aligned16(P)) return FA_ERR_MISALIGNED;
+    if (batchSize <= 0 || numHeads <= 0 || seqLenQ <= 0 || seqLenK <= 0 || dHead <= 0) return FA_ERR_BAD_SHAPE;
+    if (!std::isfinite(scale)) return FA_ERR_BAD_SCALE;
+    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP8_E4M3) return FA_ERR_UNSUPPORTED_DTYPE;
+    const int esz = elem_size(dtype);
+    if (dHead > 256 || (dHead * esz) % 16 != 0) return FA_ERR_UNSUPPORTED_DHEAD;
+    if (!strides_ok(sQ, esz, dHead) || !strides_ok(sK, esz, dHead)) return FA_ERR_BAD_STRIDE;
+    WeightsParams p;
+    p.Q = Q; p.K = K; p.lse = LSE; p.P = P;
+    p.qB = sQ ? sQ->strideB : (int64_t)numHeads * seqLenQ * dHead; p.qH = sQ ? sQ->strideH : (int64_t)seqLenQ * dHead;
+    p.qS = sQ ? sQ->strideS : dHead;
+    p.kB = sK ? sK->strideB : (int64_t)numHeads * seqLenK * dHead; p.kH = sK ? sK->strideH : (int64_t)seqLenK * dHead;
+    p.kS = sK ? sK->strideS : dHead;
+    p.H = numHeads; p.Sq = seqLenQ; p.Sk = seqLenK; p.d = dHead;
+    p.nQ = (seqLenQ + 15) / 16; p.nK = (seqLenK + 63) / 64;
+    p.scale = scale; p.causal = is_causal;
+    const int64_t blocks = (int64_t)batchSize * numHeads * p.nQ * p.nK;
+    if (blocks > INT32_MAX) return FA_ERR_BAD_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int lds = weights_lds_bytes(dHead);
+    if (dtype == FA_DTYPE_F32) hipLaunchKernelGGL((attn_weights_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    else if (dtype == FA_DTYPE_BF16) hipLaunchKernelGGL((attn_weights_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((attn_weights_kernel<fp8_t>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    return (int)hipGetLastError();
 }
 
 int flash_attention_plan(int batchSize, int numHeads, int seqLen, int dHead, bool is_causal, int dtype,

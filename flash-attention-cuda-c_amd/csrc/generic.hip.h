@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void fwd_generic_kernel(const Params p, const 
     int g, qb;
     if (!unit_of_block(p, CAUSAL, g, qb)) return;
     const int b = g / p.H, h = g - b * p.H;
-    const int S = p.S;
+    const int S = p.S, Sk = p.Sk;
     const InT* Qh = (const InT*)p.Q + b * p.qB + h * p.qH;
     const InT* Kh = (const InT*)p.K + b * p.kB + h * p.kH;
     const InT* Vh = (const InT*)p.V + b * p.vB + h * p.vH;
@@ -61,12 +61,12 @@ __global__ __launch_bounds__(256) void fwd_generic_kernel(const Params p, const 
     float m = -INFINITY, l = 0.f;
 
     const int q_last = min(S, q0 + BQ) - 1;
-    const int kv_end = CAUSAL ? q_last + 1 : S;       // keys [0, kv_end) are needed by this block
+    const int kv_end = CAUSAL ? min(q_last + 1, Sk) : Sk;       // keys [0, kv_end) are needed by this block
     for (int kv0 = 0; kv0 < kv_end; kv0 += BK) {
         __syncthreads();                              // previous tile fully consumed (and Q visible)
         for (int idx = tid; idx < BK * d; idx += NT) {
             const int r = idx / d, c = idx - r * d;
-            const int src = min(kv0 + r, S - 1);
+            const int src = min(kv0 + r, Sk - 1);
             Ks[r * (d + 1) + c] = elem_traits<InT>::load(Kh + src * p.kS + c);
             Vs[r * d + c] = elem_traits<InT>::load(Vh + src * p.vS + c);
         }
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void fwd_generic_kernel(const Params p, const 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int key = kv0 + sub + 8 * i;
-            const bool masked = key >= S || (CAUSAL && key > qi);   // utils.cuh:43: k > q
+            const bool masked = key >= Sk || (CAUSAL && key > qi);   // utils.cuh:43: k > q
             s[i] = masked ? -INFINITY : s[i] * p.scale;
             mx = fmaxf(mx, s[i]);
         }

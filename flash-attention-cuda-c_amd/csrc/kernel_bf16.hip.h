@@ -54,7 +54,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
     using G = TileGeom<C::D, C::ESZ>;
     constexpr bool CAUSAL = C::CAUSAL;
     constexpr int KVBLK = 64, SLOT = G::SLOT, KT = G::K_TILE;
-    const int S = p.S;
+    const int S = p.Sk;   // key bound of the masks
     unsigned long long tp0 = 0, tp1 = 0, tp2 = 0;
     if constexpr (C::STAMP) tp0 = cycle_stamp();
     w.init();
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = g / p.H, h = g - b * p.H;
-    const int S = p.S;
+    const int S = p.S, Sk = p.Sk;
 
     const char* Qh = (const char*)p.Q + (b * p.qB + h * p.qH) * ESZ;
     const char* Kh = (const char*)p.K + (b * p.kB + h * p.kH) * ESZ;
@@ -146,14 +146,15 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
     constexpr int WROWS = 32 * C::R;                // query rows per wave
     const int q_row0 = qb * QBLK + wave * WROWS;    // first query row of this wave
     const int q_end = min(S, (qb + 1) * QBLK);      // one past the last query row of the block
-    const int n_tiles = CAUSAL ? (q_end + KVBLK - 1) / KVBLK : (S + KVBLK - 1) / KVBLK;
+    const int k_tiles = (Sk + KVBLK - 1) / KVBLK;
+    const int n_tiles = CAUSAL ? min(k_tiles, (q_end + KVBLK - 1) / KVBLK) : k_tiles;
     // tiles this wave computes: all (non-causal) or up to the diagonal of its last row (causal)
     const bool wave_live = q_row0 < S;
     const int my_tiles = !wave_live ? 0 : (CAUSAL ? min(n_tiles, (q_row0 + WROWS - 1) / KVBLK + 1) : n_tiles);
 
     WaveCompute<C> w;
     typename WaveCompute<C>::Stage st;
-    st.init(Kh, Vh, kSb, vSb, S, wave, lane);
+    st.init(Kh, Vh, kSb, vSb, Sk, wave, lane);
     st.load_all(0);                                 // tile 0 and Q travel together (one HBM round trip)
     w.load_q(Qh, qSb, q_row0, S, lane);
     w.pin_q();

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void fwd_f32_mfma_kernel(const Params p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = g / p.H, hd = g - b * p.H;
-    const int S = p.S;
+    const int S = p.S, Sk = p.Sk;
     const int h = lane >> 5, r31 = lane & 31;
 
     const char* Qh = (const char*)p.Q + (b * p.qB + hd * p.qH) * 4;
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256, 2) void fwd_f32_mfma_kernel(const Params p) {
 
     const int q_row0 = qb * QBLK + wave * 32;
     const int q_end = min(S, (qb + 1) * QBLK);
-    const int n_tiles = CAUSAL ? (q_end + KVBLK - 1) / KVBLK : (S + KVBLK - 1) / KVBLK;
+    const int k_tiles = (Sk + KVBLK - 1) / KVBLK;
+    const int n_tiles = CAUSAL ? min(k_tiles, (q_end + KVBLK - 1) / KVBLK) : k_tiles;
     const bool wave_live = q_row0 < S;
     const int my_tiles = !wave_live ? 0 : (CAUSAL ? min(n_tiles, (q_row0 + 31) / KVBLK + 1) : n_tiles);
 
@@ -77,8 +78,8 @@ __global__ __launch_bounds__(256, 2) void fwd_f32_mfma_kernel(const Params p) {
     }
 
     // staging: a wave-instruction = 8 keys x 128 bytes; wave w owns keys 8w..8w+7; load i = 128-byte piece i
-    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (int)(S * kSb), 0x00020000);
-    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (int)(S * vSb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (int)(Sk * kSb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (int)(Sk * vSb), 0x00020000);
     const int skey = 8 * wave + (lane & 7), schunk = lane >> 3;      // 16-byte chunk within the 128-byte piece
     const int koff = skey * (int)kSb + schunk * 16, voff = skey * (int)vSb + schunk * 16;
     const int ktile = (int)(KVBLK * kSb), vtile = (int)(KVBLK * vSb);
@@ -135,9 +136,9 @@ __global__ __launch_bounds__(256, 2) void fwd_f32_mfma_kernel(const Params p) {
                 for (int i = 0; i < 4; ++i) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[i], qv[v][i], s, 0, 0, 0);
             }
             // ---- mask (diagonal / ragged tile) ----
-            if ((CAUSAL && kv0 + KVBLK - 1 > q_row0) || kv0 + KVBLK > S) {
+            if ((CAUSAL && kv0 + KVBLK - 1 > q_row0) || kv0 + KVBLK > Sk) {
                 const int qi = q_row0 + r31;
-                const int lim = CAUSAL ? (qi < S - 1 ? qi : S - 1) : S - 1;
+                const int lim = CAUSAL ? (qi < Sk - 1 ? qi : Sk - 1) : Sk - 1;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) s[k] = (kv0 + acc_row(k, h)) > lim ? -INFINITY : s[k];
             }

@@ -33,7 +33,8 @@ struct Params {
     int64_t kB, kH, kS;
     int64_t vB, vH, vS;
     int64_t oB, oH, oS;
-    int B, H, S;
+    int B, H, S;      // S = query rows per head
+    int Sk;           // keys (rows of K and V) per head; == S for self-attention
     int nQ;           // query blocks per head
     int units;        // B*H*nQ
     int cpx;          // ceil(units / 8): work units per XCD group

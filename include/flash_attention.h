@@ -119,6 +119,36 @@ int flash_attention_lse(const void* Q, const void* K, const void* V, void* O, fl
                         float scale, bool is_causal, int dtype, int o_dtype, void* stream);
 
 /*
+ * flash_attention_cross -- the full argument list of the reference's first (commented-out) API,
+ * kernels/FlashAttention.cuh:18-28: separate seqLenQ / seqLenK, the L/M statistic, per-tensor strides.
+ *   Q, O   [batchSize, numHeads, seqLenQ, dHead]      K, V   [batchSize, numHeads, seqLenK, dHead]
+ *   LSE    fp32 [batchSize, numHeads, seqLenQ] or NULL;   sQ..sO  element strides or NULL (dense)
+ * Cross-attention, decode against a longer key/value cache (seqLenQ < seqLenK) and chunked prefill all
+ * go through here.  is_causal keeps the reference's predicate on ABSOLUTE row indices -- key k is masked
+ * when k > q (kernels/utils.cuh:43) -- i.e. the mask is top-left aligned; query q sees keys
+ * 0..min(q, seqLenK-1).  (A caller that wants the last query aligned with the last key offsets its K/V
+ * view or runs non-causal over the prefix it may see.)
+ */
+int flash_attention_cross(const void* Q, const void* K, const void* V, void* O, float* LSE,
+                          int batchSize, int numHeads, int seqLenQ, int seqLenK, int dHead,
+                          float scale, bool is_causal, int dtype, int o_dtype,
+                          const fa_strides* sQ, const fa_strides* sK, const fa_strides* sV,
+                          const fa_strides* sO, void* stream);
+
+/*
+ * flash_attention_weights -- the attention matrix the reference's oracle returns next to its output
+ * (check.py:20,25 `attn`, printed by its demo at :42).  The fused kernel never stores it; this call
+ * rebuilds it from Q, K and the LSE a flash_attention_lse / flash_attention_cross call produced:
+ *     P[b,h,q,k] = exp(scale * <Q[b,h,q], K[b,h,k]> - LSE[b,h,q]),   0 where is_causal hides k > q
+ * P is a dense fp32 [batchSize, numHeads, seqLenQ, seqLenK] device buffer (mind its size: this is an
+ * inspection path for small seqLen).  Any dHead <= 256 with 16-byte rows; sQ / sK as above or NULL.
+ */
+int flash_attention_weights(const void* Q, const void* K, const float* LSE, float* P,
+                            int batchSize, int numHeads, int seqLenQ, int seqLenK, int dHead,
+                            float scale, bool is_causal, int dtype,
+                            const fa_strides* sQ, const fa_strides* sK, void* stream);
+
+/*
  * Launch-geometry policy -- the counterpart of the reference's helpers.hpp:8-36
  * (calculateSizeBlockQ / calculateSizeBlockKV / getNumCta, which return constants there).
  * Fills the tile sizes and grid the library will use for this problem; returns 0 or FA_ERR_*.

@@ -163,21 +163,22 @@ def lse_numpy(Q, K, scale=None, causal=False):
         scale = 1.0 / np.sqrt(d)
     s = Q @ np.swapaxes(K, -1, -2) * scale
     if causal:
-        s = np.where(np.triu(np.ones((S, S), dtype=bool), 1), -np.inf, s)
+        s = np.where(np.triu(np.ones((S, K.shape[-2]), dtype=bool), 1), -np.inf, s)
     mx = s.max(axis=-1, keepdims=True)
     return (mx + np.log(np.exp(s - mx).sum(axis=-1, keepdims=True)))[..., 0]
 
 
 def attention_numpy(Q, K, V, scale=None, causal=False):
     """Dense [B,H,S,d] attention in numpy float64; causal masks key k > query q
-    (tests/main.cu:81, kernels/utils.cuh:43)."""
+    (tests/main.cu:81, kernels/utils.cuh:43).  K, V may have a different row count than Q (the
+    seqLenQ / seqLenK of kernels/FlashAttention.cuh:23); the mask stays on absolute indices."""
     Q, K, V = (np.asarray(a, dtype=np.float64) for a in (Q, K, V))
     S, d = Q.shape[-2:]
     if scale is None:
         scale = 1.0 / np.sqrt(d)
     s = Q @ np.swapaxes(K, -1, -2) * scale
     if causal:
-        s = np.where(np.triu(np.ones((S, S), dtype=bool), 1), -np.inf, s)
+        s = np.where(np.triu(np.ones((S, K.shape[-2]), dtype=bool), 1), -np.inf, s)
     s = s - s.max(axis=-1, keepdims=True)
     p = np.exp(s)
     p /= p.sum(axis=-1, keepdims=True)

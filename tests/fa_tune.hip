@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
     p.qS = p.kS = p.vS = p.oS = d;
     p.qH = p.kH = p.vH = p.oH = (int64_t)S * d;
     p.qB = p.kB = p.vB = p.oB = (int64_t)H * S * d;
-    p.B = B; p.H = H; p.S = S;
+    p.B = B; p.H = H; p.S = S; p.Sk = S;
     p.nQ = (S + 255) / 256;
     p.units = BH * p.nQ;
     p.cpx = (p.units + 7) / 8;

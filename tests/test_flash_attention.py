@@ -72,6 +72,46 @@ def test_known_answer_checkpy_demo(golden):
     np.testing.assert_allclose(out.cpu().numpy(), golden.load("F1", "out"), atol=1e-6)
 
 
+def test_attn_matrix_against_checkpy(golden):
+    """check.py:25 returns (output, attn).  attn rebuilt on the GPU from the fused kernel's LSE against the
+    matrices check.py itself produced: F1 (demo, attn == 0.25), F3 (two heads, random), F0 (row sums == 1)."""
+    one = torch.from_numpy(golden.load("F1", "Q")).to(DEV)
+    out, attn = fa.multi_head_attention(one, one, one, 2, return_attn=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(attn.cpu().numpy(), golden.load("F1", "attn"), atol=1e-6)       # check.py:42 prints this
+    np.testing.assert_allclose(out.cpu().numpy(), golden.load("F1", "out"), atol=1e-6)
+    Q, K, V = (torch.from_numpy(golden.load("F3", k)).to(DEV) for k in "QKV")
+    out, attn = fa.multi_head_attention(Q, K, V, 2, return_attn=True)
+    torch.cuda.synchronize()
+    assert attn.shape == golden.load("F3", "attn").shape
+    np.testing.assert_allclose(attn.cpu().numpy(), golden.load("F3", "attn"), rtol=2e-4, atol=1e-7)
+    check(out.cpu().numpy(), golden.load("F3", "out"), 2e-5, 1e-4)
+    Q, K, V = (torch.from_numpy(golden.load("F0", k)).to(DEV) for k in "QKV")
+    out, attn = fa.multi_head_attention(Q, K, V, 1, return_attn=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(attn.sum(-1).cpu().numpy(), golden.load("F0", "attn_rowsum"), atol=2e-5)
+    # attn @ V reproduces the fused kernel's output (check.py:21)
+    check(torch.matmul(attn, V.view(1, 128, 1, 64).transpose(1, 2)).transpose(1, 2).reshape(1, 128, 64).cpu().numpy(),
+          out.cpu().numpy(), 2e-5, 1e-4)
+
+
+def test_attn_matrix_causal_and_rectangular():
+    """Causal (k > q entries exactly 0) and seqLenQ != seqLenK, bf16 inputs, against the float64 oracle."""
+    B, H, Sq, Sk, d = 1, 2, 70, 150, 128
+    Q, K, V = randn((B, H, Sq, d), 50, torch.bfloat16), randn((B, H, Sk, d), 51, torch.bfloat16), randn((B, H, Sk, d), 52, torch.bfloat16)
+    for causal in (False, True):
+        O, lse = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, out_dtype=torch.float32, return_lse=True)
+        P = fa.attention_weights(Q.to(DEV), K.to(DEV), lse, is_causal=causal)
+        torch.cuda.synchronize()
+        s = Q.double().numpy() @ K.double().numpy().swapaxes(-1, -2) / np.sqrt(d)
+        if causal:
+            s = np.where(np.triu(np.ones((Sq, Sk), dtype=bool), 1), -np.inf, s)
+        ref = np.exp(s - s.max(-1, keepdims=True)); ref /= ref.sum(-1, keepdims=True)
+        np.testing.assert_allclose(P.cpu().numpy(), ref, rtol=3e-3, atol=1e-6)    # LSE carries the bf16-P row-sum error
+        if causal:
+            assert (P.cpu().numpy()[..., np.triu(np.ones((Sq, Sk), dtype=bool), 1)] == 0).all()
+
+
 # ------------------------------------------------------------------ golden vectors (from check.py)
 @pytest.mark.parametrize("name", ["F0", "F3", "F4", "F6"])
 def test_golden_fp32_through_checkpy_api(golden, name):
@@ -262,6 +302,63 @@ def test_fp32_mfma_path_spike_and_outputs():
     # peaky golden fixture F6 gets in test_oracle.py
     Q6, K6 = Q * 6, K * 6
     check(run_gpu(Q6, K6, V, False), oracle.attention(Q6.numpy(), K6.numpy(), V.numpy()), 2e-4, 2e-4)
+
+
+CROSS_CASES = [  # dtype, B, H, Sq, Sk, d, causal
+    (torch.bfloat16, 1, 2, 1, 1000, 128, False),      # decode: one query against a key/value cache
+    (torch.bfloat16, 2, 2, 300, 1111, 128, False),
+    (torch.bfloat16, 1, 2, 700, 130, 128, True),      # more queries than keys: rows q >= Sk see every key
+    (torch.bfloat16, 1, 3, 100, 517, 64, True),       # top-left mask: only keys 0..q
+    (torch.float32, 1, 2, 260, 90, 128, True),        # fp32 MFMA kernel
+    (torch.float32, 2, 1, 33, 400, 64, False),
+    (torch.float32, 1, 2, 50, 77, 40, True),          # generic kernel
+    (torch.bfloat16, 1, 2, 64, 200, 80, False),       # generic kernel, bf16 inputs
+]
+
+
+@pytest.mark.parametrize("dtype,B,H,Sq,Sk,d,causal", CROSS_CASES)
+def test_cross_lengths(dtype, B, H, Sq, Sk, d, causal):
+    """seqLenQ != seqLenK (the reference's first API, kernels/FlashAttention.cuh:23, never live there: the
+    reference holds no fixture for it, so parity here is against the oracle's float64 restatement of the same
+    formula with the k > q mask of kernels/utils.cuh:43 on absolute indices).  O and LSE."""
+    Q = randn((B, H, Sq, d), 60, dtype)
+    K = randn((B, H, Sk, d), 61, dtype)
+    V = randn((B, H, Sk, d), 62, dtype)
+    Qf, Kf, Vf = (t.float().numpy() for t in (Q, K, V))
+    ref = oracle.attention_numpy(Qf, Kf, Vf, causal=causal)
+    O, lse = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, out_dtype=torch.float32, return_lse=True)
+    torch.cuda.synchronize()
+    atol, rtol = tol_for(dtype, torch.float32)
+    check(O.cpu().numpy(), ref, atol, rtol)
+    np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(Qf, Kf, causal=causal), rtol=2e-6,
+                               atol=2e-4 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.skipif(FP8 is None, reason="torch build without float8_e4m3fn")
+def test_cross_lengths_fp8_and_strided_cache():
+    """fp8 inputs with Sq < Sk, and K/V given as a strided window of a longer cache buffer."""
+    B, H, Sq, Sk, d = 1, 2, 130, 900, 128
+    Q = randn((B, H, Sq, d), 70, torch.float32).to(FP8)
+    cache_k = randn((B, H, 1024, d), 71, torch.float32).to(FP8)
+    cache_v = randn((B, H, 1024, d), 72, torch.float32).to(FP8)
+    Kd, Vd = cache_k.to(DEV)[:, :, :Sk], cache_v.to(DEV)[:, :, :Sk]     # views: head stride 1024*d
+    assert not Kd.is_contiguous()
+    O = fa.flash_attention(Q.to(DEV), Kd, Vd, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    ref = oracle.attention_numpy(Q.float().numpy(), cache_k[:, :, :Sk].float().numpy(), cache_v[:, :, :Sk].float().numpy())
+    check(O.cpu().numpy(), ref, 4e-3, 4e-3, rms=1e-3)
+
+
+def test_cross_equals_self_attention_on_the_same_prefix():
+    """Causal self-attention rows [0, n) depend only on keys [0, n): running the first n queries against all
+    Sk keys (cross entry point, causal) must reproduce the first n rows of the square problem bit for bit
+    when n is a multiple of the query block."""
+    B, H, S, d, n = 1, 2, 1024, 128, 512
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16).to(DEV) for s in (80, 81, 82))
+    full = fa.flash_attention(Q, K, V, is_causal=True, out_dtype=torch.float32)
+    part = fa.flash_attention(Q[:, :, :n].contiguous(), K, V, is_causal=True, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert torch.equal(part, full[:, :, :n])
 
 
 def test_heads_are_independent():

@@ -131,3 +131,21 @@ def test_bf16_and_e4m3_rounding_match_torch(golden):
             continue
         assert L.oracle_f32_to_e4m3fn(v) == b or v == 0.0
     assert L.oracle_f32_to_e4m3fn(1e9) == 0x7E and L.oracle_f32_to_e4m3fn(-1e9) == 0xFE
+
+
+def test_numpy_oracle_rectangular_mask():
+    """seqLenQ != seqLenK (kernels/FlashAttention.cuh:23): the k > q predicate of kernels/utils.cuh:43 stays on
+    absolute indices.  Each row checked against an explicit per-row softmax over its visible keys."""
+    rng = np.random.default_rng(5)
+    for Sq, Sk in ((5, 9), (9, 5), (1, 7)):
+        Q = rng.standard_normal((1, 2, Sq, 8)); K = rng.standard_normal((1, 2, Sk, 8)); V = rng.standard_normal((1, 2, Sk, 8))
+        for causal in (False, True):
+            O = oracle.attention_numpy(Q, K, V, causal=causal)
+            L = oracle.lse_numpy(Q, K, causal=causal)
+            for h in range(2):
+                for q in range(Sq):
+                    nk = min(q + 1, Sk) if causal else Sk
+                    s = K[0, h, :nk] @ Q[0, h, q] / np.sqrt(8)
+                    w = np.exp(s - s.max()); w /= w.sum()
+                    np.testing.assert_allclose(O[0, h, q], w @ V[0, h, :nk], rtol=1e-12, atol=1e-12)
+                    np.testing.assert_allclose(L[0, h, q], np.log(np.exp(s).sum()), rtol=1e-12)
