@@ -5,6 +5,8 @@
 // tests/main.cu:51-64.  Written for gfx950 only: hipcc --offload-arch=gfx950.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -69,6 +71,20 @@ static int validate(const void* Q, const void* K, const void* V, void* O, int B,
     return FA_OK;
 }
 
+// Compute units of the current device (persistent grid = one workgroup per CU).  256 on MI355X, which is
+// also the answer when no device is visible (flash_attention_plan is callable on a build machine).
+static int device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_dtype, float scale,
                      fa_launch_plan* plan) {
     (void)causal; (void)o_dtype;
@@ -91,9 +107,11 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
         plan->threads = 512;
         // 3-slot ring of [K image (input type) | V image (bf16)]
         plan->lds_bytes = 3 * plan->kv_block_rows * d * ((mfma_fp8 ? 1 : 2) + 2);
+        // persistent grid: one workgroup per CU (8 XCD groups x CUs/8), each walking ceil(units/grid) units;
+        // with fewer units than CUs, one workgroup per unit
         const int nQ = getNumCta(S, plan->q_block_rows);
         const int64_t units = (int64_t)B * H * nQ;
-        plan->grid = (int)(8 * ((units + 7) / 8));
+        plan->grid = (int)(8 * std::min<int64_t>((units + 7) / 8, device_cus() / 8));
     } else {
         plan->kernel_id = 0;
         plan->q_block_rows = GenericCfg::BQ;
@@ -120,9 +138,9 @@ static hipError_t launch_mfma(const Params& p, const fa_launch_plan& plan, hipSt
 
 template <int D, bool CAUSAL, int ESZ>
 static hipError_t launch_mfma_out(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
-    if (o_dtype == FA_DTYPE_F32) return launch_mfma<KernelCfg<D, CAUSAL, float, ESZ>>(p, plan, st);
-    if (o_dtype == FA_DTYPE_BF16) return launch_mfma<KernelCfg<D, CAUSAL, __bf16, ESZ>>(p, plan, st);
-    return launch_mfma<KernelCfg<D, CAUSAL, _Float16, ESZ>>(p, plan, st);
+    if (o_dtype == FA_DTYPE_F32) return launch_mfma<ProdCfg<D, CAUSAL, float, ESZ>>(p, plan, st);
+    if (o_dtype == FA_DTYPE_BF16) return launch_mfma<ProdCfg<D, CAUSAL, __bf16, ESZ>>(p, plan, st);
+    return launch_mfma<ProdCfg<D, CAUSAL, _Float16, ESZ>>(p, plan, st);
 }
 
 template <class Cfg>
@@ -181,6 +199,7 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
     p.nQ = getNumCta(S, plan.q_block_rows);
     p.units = B * H * p.nQ;
     p.cpx = (p.units + 7) / 8;
+    p.jpx = plan.grid / 8;
     p.dbg = nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;

@@ -27,8 +27,9 @@
 namespace fa {
 
 template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, bool STAMP_ = false, bool OPTIMISTIC_ = true, int NPRE_ = 4,
-          int VPRE_ = 2, int THR_ = 8, int R_ = 1, bool ASM_MFMA_ = false, bool VALU_FIRST_ = true>
+          int VPRE_ = 2, int THR_ = 8, int R_ = 1, bool ASM_MFMA_ = false, bool VALU_FIRST_ = true, bool PERSIST_ = false>
 struct KernelCfg {
+    static constexpr bool PERSIST = PERSIST_;        // one workgroup per CU walks a static list of units (see work_unit)
     static constexpr bool VALU_FIRST = VALU_FIRST_;  // phase-A slots issue their softmax slice before the MFMA
     static constexpr bool ASM_MFMA = ASM_MFMA_;      // inline-asm MFMAs with dictated register classes (for R = 2)
     static constexpr int D = D_;
@@ -44,6 +45,10 @@ struct KernelCfg {
     static constexpr int THR = THR_;                 // lazy-rescale threshold of the tracked pass, log2 units
     static constexpr int LDS_BYTES = 3 * TileGeom<D_, ESZ_>::SLOT;
 };
+
+// What the library launches: optimistic pass, VALU-first slots, persistent grid.
+template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false>
+using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, STAMP, true, 4, 2, 8, 1, false, true, true>;
 
 // One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the
 // result has to be recomputed with max tracking (only ever true for TRACK = false).
@@ -118,70 +123,133 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
     }
 }
 
+// Work assignment.  Non-persistent: one unit per workgroup (loaders.hip.h: unit_of_block).  Persistent: the
+// grid is one workgroup per CU; XCD group x = bid & 7 still owns the contiguous units [x*cpx, (x+1)*cpx), and
+// its jpx workgroups walk them in rounds of jpx consecutive units -- at any moment the group works on a few
+// adjacent heads, whose K/V stay in that XCD's L2.  Odd rounds run in reverse order ("snake"): under the
+// causal mask a head's query blocks are listed heaviest first, so workgroup j gets cost c in one round and
+// (max+1-c) in the next -- a static schedule whose per-workgroup totals are equal when nQ divides jpx.
+template <class C>
+__device__ __forceinline__ bool work_unit(const Params& p, int round, int& g, int& qb) {
+    const int bid = blockIdx.x;
+    int idx = bid >> 3;
+    if constexpr (C::PERSIST) {
+        idx = round * p.jpx + ((round & 1) ? p.jpx - 1 - idx : idx);
+        if (idx >= p.cpx) return false;
+    } else if (round > 0) {
+        return false;
+    }
+    const int u = (bid & 7) * p.cpx + idx;
+    if (u >= p.units) return false;
+    g = u / p.nQ;
+    qb = u - g * p.nQ;
+    if (C::CAUSAL) qb = p.nQ - 1 - qb;  // heaviest query blocks of a head first
+    return true;
+}
+
+// Everything a wave needs to know about one unit = one 256-row query block of one (batch, head).
+template <class C>
+struct UnitCtx {
+    const char *Qh, *Kh, *Vh;
+    char* Oh;
+    float* lse_head;
+    int q_row0, n_tiles, my_tiles;
+    bool wave_live;
+    __device__ __forceinline__ void set(const Params& p, int g, int qb, int wave) {
+        constexpr int ESZ = C::ESZ, KVBLK = 64, QBLK = 256, WROWS = 32 * C::R;
+        const int b = g / p.H, h = g - b * p.H;
+        Qh = (const char*)p.Q + (b * p.qB + h * p.qH) * ESZ;
+        Kh = (const char*)p.K + (b * p.kB + h * p.kH) * ESZ;
+        Vh = (const char*)p.V + (b * p.vB + h * p.vH) * ESZ;
+        Oh = (char*)p.O + (b * p.oB + h * p.oH) * (int64_t)sizeof(typename C::OutT);
+        lse_head = p.lse ? p.lse + (int64_t)g * p.S : nullptr;
+        q_row0 = qb * QBLK + wave * WROWS;              // first query row of this wave
+        const int q_end = min(p.S, (qb + 1) * QBLK);    // one past the last query row of the block
+        const int k_tiles = (p.Sk + KVBLK - 1) / KVBLK;
+        n_tiles = C::CAUSAL ? min(k_tiles, (q_end + KVBLK - 1) / KVBLK) : k_tiles;
+        // tiles this wave computes: all (non-causal) or up to the diagonal of its last row (causal)
+        wave_live = q_row0 < p.S;
+        my_tiles = !wave_live ? 0 : (C::CAUSAL ? min(n_tiles, (q_row0 + WROWS - 1) / KVBLK + 1) : n_tiles);
+    }
+};
+
 template <class C>
 __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_kernel(const Params p) {
     constexpr int D = C::D, ESZ = C::ESZ;
-    constexpr bool CAUSAL = C::CAUSAL;
     using OutT = typename C::OutT;
-    constexpr int KVBLK = 64, QBLK = 256;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     lds_ptr smem = (lds_ptr)smem_raw;
 
-    int g, qb;
-    if (!unit_of_block(p, CAUSAL, g, qb)) return;
+    int g, qb, round = 0;
+    if (!work_unit<C>(p, 0, g, qb)) return;
     unsigned long long t_kernel0 = 0;
     if constexpr (C::STAMP) t_kernel0 = cycle_stamp();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = g / p.H, h = g - b * p.H;
     const int S = p.S, Sk = p.Sk;
-
-    const char* Qh = (const char*)p.Q + (b * p.qB + h * p.qH) * ESZ;
-    const char* Kh = (const char*)p.K + (b * p.kB + h * p.kH) * ESZ;
-    const char* Vh = (const char*)p.V + (b * p.vB + h * p.vH) * ESZ;
-    char* Oh = (char*)p.O + (b * p.oB + h * p.oH) * (int64_t)sizeof(OutT);
-    float* lse_head = p.lse ? p.lse + (int64_t)g * S : nullptr;
     const int64_t qSb = p.qS * ESZ, kSb = p.kS * ESZ, vSb = p.vS * ESZ, oSb = p.oS * (int64_t)sizeof(OutT);
-
     constexpr int WROWS = 32 * C::R;                // query rows per wave
-    const int q_row0 = qb * QBLK + wave * WROWS;    // first query row of this wave
-    const int q_end = min(S, (qb + 1) * QBLK);      // one past the last query row of the block
-    const int k_tiles = (Sk + KVBLK - 1) / KVBLK;
-    const int n_tiles = CAUSAL ? min(k_tiles, (q_end + KVBLK - 1) / KVBLK) : k_tiles;
-    // tiles this wave computes: all (non-causal) or up to the diagonal of its last row (causal)
-    const bool wave_live = q_row0 < S;
-    const int my_tiles = !wave_live ? 0 : (CAUSAL ? min(n_tiles, (q_row0 + WROWS - 1) / KVBLK + 1) : n_tiles);
 
+    UnitCtx<C> cur;
+    cur.set(p, g, qb, wave);
     WaveCompute<C> w;
     typename WaveCompute<C>::Stage st;
-    st.init(Kh, Vh, kSb, vSb, Sk, wave, lane);
+    st.init(cur.Kh, cur.Vh, kSb, vSb, Sk, wave, lane);
     st.load_all(0);                                 // tile 0 and Q travel together (one HBM round trip)
-    w.load_q(Qh, qSb, q_row0, S, lane);
-    w.pin_q();
+    w.load_q(cur.Qh, qSb, cur.q_row0, S, lane);
     unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if constexpr (C::STAMP) acc[7] = cycle_stamp() - t_kernel0;
 
-    if constexpr (C::OPTIMISTIC) {
-        if (attention_pass<C, false>(p, w, st, smem, n_tiles, my_tiles, q_row0, lane, acc, true))
-            attention_pass<C, true>(p, w, st, smem, n_tiles, my_tiles, q_row0, lane, acc, false);
-    } else {
-        attention_pass<C, true>(p, w, st, smem, n_tiles, my_tiles, q_row0, lane, acc, true);
-    }
+    while (true) {
+        unsigned long long t_q0 = 0;
+        if constexpr (C::STAMP) t_q0 = cycle_stamp();
+        w.pin_q();
+        if constexpr (C::STAMP) acc[7] += cycle_stamp() - t_q0;
 
-    unsigned long long t_ep0 = 0;
-    if constexpr (C::STAMP) t_ep0 = cycle_stamp();
-    if constexpr (sizeof(OutT) == 2) {
-        // every pass ends behind a workgroup barrier, so no wave still reads the K/V ring: reuse it
-        static_assert(256 * D * 2 <= C::LDS_BYTES, "epilogue regions must fit the ring");
-        if (wave_live) w.template store_o_lds<OutT>(smem + wave * (WROWS * D * 2), Oh, lse_head, oSb, q_row0, S, lane);
-    } else {
-        if (wave_live) w.template store_o<OutT>(Oh, lse_head, oSb, q_row0, S, lane);
+        if constexpr (C::OPTIMISTIC) {
+            if (attention_pass<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane, acc, true))
+                attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane, acc, false);
+        } else {
+            attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane, acc, true);
+        }
+
+        // Persistent grid: request the next unit's Q and tile 0 now, so their HBM round trip runs under
+        // this unit's epilogue (Q's registers and the staging registers are dead once the pass is over).
+        bool more = false;
+        UnitCtx<C> nxt;
+        if constexpr (C::PERSIST) {
+            more = work_unit<C>(p, ++round, g, qb);
+            if (more) {
+                nxt.set(p, g, qb, wave);
+                st.init(nxt.Kh, nxt.Vh, kSb, vSb, Sk, wave, lane);
+                st.load_all(0);
+                w.load_q(nxt.Qh, qSb, nxt.q_row0, S, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        unsigned long long t_ep0 = 0;
+        if constexpr (C::STAMP) t_ep0 = cycle_stamp();
+        // The epilogue's ~40 per-lane addresses must be recomputed here: hoisted out of the unit loop they
+        // would live across the tile loop, spill, and their reload (vmcnt(0)) would wait for the prefetch above.
+        int lane_e = lane;
+        if constexpr (C::PERSIST) asm volatile("" : "+v"(lane_e));
+        if constexpr (sizeof(OutT) == 2) {
+            // every pass ends behind a workgroup barrier, so no wave still reads the K/V ring: reuse it
+            static_assert(256 * D * 2 <= C::LDS_BYTES, "epilogue regions must fit the ring");
+            if (cur.wave_live)
+                w.template store_o_lds<OutT>(smem + wave * (WROWS * D * 2), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e);
+        } else {
+            if (cur.wave_live) w.template store_o<OutT>(cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e);
+        }
+        if constexpr (C::STAMP) acc[4] += cycle_stamp() - t_ep0;   // epilogue: normalise + store O (issue side)
+        if (!more) break;
+        // the next prologue overwrites ring slots that other waves' epilogue regions alias
+        if constexpr (sizeof(OutT) == 2) __syncthreads();
+        cur = nxt;
     }
     if constexpr (C::STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store tail
-        const unsigned long long t_end = cycle_stamp();
-        acc[0] = t_end - t_kernel0;       // whole workgroup lifetime of this wave
-        acc[4] = t_end - t_ep0;           // epilogue: normalise + store O
+        acc[0] = cycle_stamp() - t_kernel0;                // whole workgroup lifetime of this wave
         if (lane == 0 && p.dbg) {
 #pragma unroll
             for (int k = 0; k < 11; ++k) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + k] = acc[k];

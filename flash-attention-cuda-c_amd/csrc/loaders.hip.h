@@ -38,6 +38,7 @@ struct Params {
     int nQ;           // query blocks per head
     int units;        // B*H*nQ
     int cpx;          // ceil(units / 8): work units per XCD group
+    int jpx;          // persistent grid only: workgroups per XCD group (grid / 8)
     float scale_log2; // scale * log2(e)
     float scale;
     unsigned long long* dbg;  // diagnostic builds only (tests/fa_tune): per-wave segment cycle sums

@@ -45,6 +45,8 @@ static void fill_randn_bf16(std::vector<uint16_t>& v, uint64_t seed, double mul 
     }
 }
 
+static int g_cus = 256, g_jpx = 0;   // --jpx N: workgroups per XCD group of the persistent variants (default CUs/8)
+
 struct Variant {
     std::string name;
     std::function<void(const Params&, int grid)> launch;
@@ -57,19 +59,27 @@ static void launch_cfg(const Params& p, int grid) {
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((fwd_mfma_kernel<K>), dim3(grid), dim3(64 * K::NWAVES), K::LDS_BYTES, nullptr, p);
+    if constexpr (K::PERSIST) {
+        // one workgroup per CU (256 on MI355X), or one per unit when there are fewer units than CUs
+        Params q = p;
+        q.jpx = std::min(p.cpx, g_jpx > 0 ? g_jpx : g_cus / 8);
+        hipLaunchKernelGGL((fwd_mfma_kernel<K>), dim3(8 * q.jpx), dim3(64 * K::NWAVES), K::LDS_BYTES, nullptr, q);
+    } else {
+        hipLaunchKernelGGL((fwd_mfma_kernel<K>), dim3(grid), dim3(64 * K::NWAVES), K::LDS_BYTES, nullptr, p);
+    }
 }
 
 // KernelCfg<D, CAUSAL, OutT, ESZ, STAMP, OPTIMISTIC, NPRE, VPRE, THR>
 template <int D, bool CAUSAL>
 static std::vector<Variant> make_variants() {
     std::vector<Variant> v;
-    v.push_back({"production (optimistic, npre4 vpre2)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2>>});
-    v.push_back({"MFMA-first slots (old order)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, false>>});
+    v.push_back({"production (persistent, optimistic)", launch_cfg<ProdCfg<D, CAUSAL, __bf16>>});
+    v.push_back({"one unit per workgroup (r01 a-j)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2>>});
     v.push_back({"R=2 asm npre4 vpre2 (experimental)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 2, true, true>>});
-    v.push_back({"tracked only", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, false, 4, 2>>});
-    v.push_back({"optimistic npre6 vpre3", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 6, 3>>});
-    v.push_back({"production STAMP", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, true, true, 4, 2>>});
+    v.push_back({"tracked only (persistent)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, false, 4, 2, 8, 1, false, true, true>>});
+    v.push_back({"persistent npre6 vpre3", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 6, 3, 8, 1, false, true, true>>});
+    v.push_back({"one unit per workgroup STAMP", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, true, true, 4, 2>>});
+    v.push_back({"production STAMP", launch_cfg<ProdCfg<D, CAUSAL, __bf16, 2, true>>});
     return v;
 }
 
@@ -82,10 +92,16 @@ int main(int argc, char** argv) {
         std::string a = argv[i];
         if (a == "--rounds" && i + 1 < argc) rounds = atoi(argv[++i]);
         else if (a == "--qkscale" && i + 1 < argc) qkscale = atof(argv[++i]);
+        else if (a == "--jpx" && i + 1 < argc) g_jpx = atoi(argv[++i]);
         else if (a == "--only" && i + 1 < argc) {
             char* s = argv[++i];
             for (char* t = strtok(s, ","); t; t = strtok(nullptr, ",")) only.push_back(atoi(t));
         } else pos.push_back(atoi(argv[i]));
+    }
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8)
+            g_cus = cus;
     }
     if (pos.size() >= 5) { B = pos[0]; H = pos[1]; S = pos[2]; d = pos[3]; causal = pos[4]; }
     const int BH = B * H;
@@ -140,7 +156,7 @@ int main(int argc, char** argv) {
         }
     };
     std::vector<uint16_t> out0(n), outv(n);
-    printf("problem: B=%d H=%d S=%d d=%d causal=%d  grid=%d  rounds=%d qkscale=%g\n", B, H, S, d, causal, grid, rounds, qkscale);
+    printf("problem: B=%d H=%d S=%d d=%d causal=%d  grid=%d  rounds=%d qkscale=%g jpx=%d\n", B, H, S, d, causal, grid, rounds, qkscale, g_jpx);
     for (size_t vi = 0; vi < vars.size(); ++vi) {
         HIP_CHECK(hipMemset(dout, 0xff, n * 2));
         vars[vi].launch(p, grid);
@@ -175,6 +191,7 @@ int main(int argc, char** argv) {
     std::vector<std::vector<float>> ms(vars.size());
     for (size_t vi = 0; vi < vars.size(); ++vi) { vars[vi].launch(p, grid); vars[vi].launch(p, grid); }
     HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemset(ddbg, 0, (size_t)grid * 128 * 8));   // stamp rows: only the STAMP variant(s) timed below write them
     for (int r = 0; r < rounds; ++r)
         for (size_t vi = 0; vi < vars.size(); ++vi) {
             HIP_CHECK(hipEventRecord(e0, nullptr));
@@ -191,7 +208,7 @@ int main(int argc, char** argv) {
         double seg[12] = {0};
         for (size_t i = 0; i < (size_t)grid * 8; ++i)
             for (int k = 0; k < 12; ++k) seg[k] += (double)h[i * 16 + k];
-        if (seg[6] > 0 && !causal) {
+        if (seg[6] > 0) {
             const double nt = seg[6], nw = seg[11] > 0 ? seg[11] : 1;
             printf("  STAMP build (each stamp costs ~40-60 cycles):\n");
             printf("    per tile per wave (%.0f wave-tiles): phase A %.1f | phase B %.1f | end-of-tile %.1f | barrier %.1f | sum %.1f\n", nt,

@@ -81,7 +81,10 @@ def test_launch_plan(B, H, S, d, causal, dtype, kid, br, bc):
     assert p["kernel_id"] == kid and p["q_block_rows"] == br and p["kv_block_rows"] == bc
     n_q = -(-S // br)                                  # getNumCta: ceil, not the reference's assert
     units = B * H * n_q
-    assert p["grid"] == 8 * (-(-units // 8)) and p["grid"] >= units
+    if kid in (1, 2):      # persistent grid: one workgroup per CU (256 on MI355X) walking ceil(units/grid) units
+        assert p["grid"] == min(8 * (-(-units // 8)), 256)
+    else:
+        assert p["grid"] == 8 * (-(-units // 8)) and p["grid"] >= units
     assert p["threads"] % 64 == 0 and p["lds_bytes"] <= 160 * 1024
     if kid == 1:
         assert p["lds_bytes"] == 3 * 2 * 64 * d * 2      # 3-slot ring of K+V tiles

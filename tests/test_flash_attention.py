@@ -440,6 +440,32 @@ def _sampled_check(B, H, S, d, causal, seeds, heads, rows):
     return Q, K, V, O
 
 
+@pytest.mark.parametrize("B,H,S,d,causal,out_dtype", [
+    (3, 37, 700, 128, True, torch.bfloat16),     # 333 units on 256 workgroups: 2 ragged rounds, LDS epilogue + barrier
+    (2, 150, 300, 64, False, torch.float32),     # 600 units, 3 rounds, direct fp32 epilogue
+    (5, 61, 257, 128, True, torch.float32),      # 610 units, second query block has one live row
+])
+def test_persistent_grid_every_unit_is_computed(B, H, S, d, causal, out_dtype):
+    """More units than CUs: each workgroup walks several units (snake schedule, next unit's Q and tile 0
+    prefetched under the epilogue).  Full-tensor compare, so a skipped or doubly-assigned unit cannot hide."""
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in (95, 96, 97))
+    ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=causal)
+    atol, rtol = tol_for(torch.bfloat16, out_dtype)
+    check(run_gpu(Q, K, V, causal, out_dtype=out_dtype), ref, atol, rtol)
+
+
+def test_persistent_grid_fallback_inside_a_walk():
+    """One head in the middle of a workgroup's unit list overflows the optimistic pass (scores x12): that unit
+    is recomputed by the tracked pass and the units before / after it on the same workgroup stay right."""
+    B, H, S, d = 1, 300, 512, 128      # 600 units -> every workgroup walks 2-3 units
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in (98, 99, 100))
+    for h in (5, 140, 141, 299):
+        Q[0, h] *= 12
+        K[0, h] *= 12
+    ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=True)
+    check(run_gpu(Q, K, V, True), ref, 4e-3, 4e-3)
+
+
 def test_baseline_cfg1_full_tensor():
     """BASELINE cfg1: bf16, B=4, H=8, S=2048, d=64, non-causal -- full-tensor compare (34 GFLOP on the CPU)."""
     B, H, S, d = 4, 8, 2048, 64
