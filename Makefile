@@ -7,7 +7,7 @@ LIB      := $(PKG)/libflash_attention.so
 KSRC     := $(PKG)/csrc/FlashAttention.hip
 KHDR     := $(wildcard $(PKG)/csrc/*.h) $(PKG)/helpers.hpp include/flash_attention.h
 
-all: $(LIB) oracle $(PKG)/fa_main tests/fa_test tests/fa_tune
+all: $(LIB) oracle $(PKG)/fa_main tests/fa_test tests/fa_tune tests/micro/simd_mix tests/micro/valu_rates
 
 $(LIB): $(KSRC) $(KHDR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KSRC)
@@ -31,10 +31,14 @@ tests/fa_test: tests/main.cpp $(LIB) oracle/liboracle_attention.so
 tests/fa_tune: tests/fa_tune.hip $(KHDR) oracle/liboracle_attention.so
 	$(HIPCC) $(HIPFLAGS) -o $@ tests/fa_tune.hip -Loracle -loracle_attention -Wl,-rpath,'$$ORIGIN/../oracle'
 
+# microbenchmarks: instruction issue rates; how busy 2 waves keep one SIMD's MFMA pipe; power-limited ceilings
+tests/micro/%: tests/micro/%.hip
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++20 -o $@ $<
+
 asm: $(KSRC) $(KHDR)
 	mkdir -p build && $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/FlashAttention.s $(KSRC)
 
 clean:
-	rm -f $(LIB) $(PKG)/fa_main tests/fa_test oracle/liboracle_attention.so
+	rm -f $(LIB) $(PKG)/fa_main tests/fa_test tests/fa_tune tests/micro/simd_mix tests/micro/valu_rates oracle/liboracle_attention.so
 	rm -rf build
 .PHONY: all oracle clean asm

@@ -55,6 +55,23 @@ def measured_traffic(workload):
         return None
 
 
+def power_limited_ceiling():
+    """This device's throughput ceiling as the power limit sets it: tests/micro/simd_mix --ceiling runs, on every
+    CU, 2 waves per SIMD of (a) back-to-back v_mfma_f32_32x32x16_bf16 and (b) the attention kernel's own
+    per-MFMA instruction mix (softmax VALU ops + K / V^T LDS reads), both on RANDOM bf16 operands, pipe >= 90 %
+    busy -- the chip then holds 1.3-1.7 GHz, not the 2.4 GHz behind the 2516.6 TFLOP/s nominal peak.  A separate
+    child process started after the timed region; None if the microbenchmark is not built."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "micro", "simd_mix")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "--ceiling"], capture_output=True, text=True, timeout=120, check=True).stdout
+        return json.loads(out.strip().splitlines()[-1])
+    except Exception:   # noqa: BLE001 -- a diagnostic extra must never fail the benchmark
+        return None
+
+
 def cpu_baseline(S, d, causal, budget_s=12.0):
     """Naive fp32 attention (the oracle, a port of tests/main.cu:74-91 / check.py:19-21) on the host
     cores, on a bounded sample: as many whole heads of the workload's (S, d) as fit ~budget_s."""
@@ -88,8 +105,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the power-limited-ceiling microbenchmark")
     ap.add_argument("--out-dtype", default="bf16", choices=["bf16", "f32"])
     args = ap.parse_args()
+
+    # The ceiling microbenchmark is a separate GPU program: run it as a child BEFORE this process touches the GPU
+    # (no exec from a process that has initialised HIP).  Single-GPU runs only.
+    ceil = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_ceiling and args.workload != "cfg3":
+        ceil = power_limited_ceiling()
 
     import torch
     import torch.distributed as dist
@@ -182,6 +206,10 @@ def main():
                          "algorithmic_hbm_GBps": round(heads_local * S * d * (3 * Q.element_size() + O.element_size())
                                                        / (kernel_ms_max * 1e-3) / 1e9, 1)},
         }
+        if ceil:
+            line["roofline"]["power_limited"] = dict(
+                ceil, frac_of_mfma_only=round(achieved / ceil["mfma_only_random_bf16_tflops"], 4),
+                frac_of_attention_mix=round(achieved / ceil["attention_mix_random_bf16_tflops"], 4))
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(S, d, causal)
         print(json.dumps(line), flush=True)

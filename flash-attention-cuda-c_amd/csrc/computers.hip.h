@@ -74,6 +74,8 @@ struct WaveCompute {
     bf16x8 vf[VPRE + 1];
     uint32_t pw[R][16];   // P(t) as packed bf16 pairs: word 4g+w = elements 8g+2w, 8g+2w+1
     float sum_a[R], sum_b[R], mx_a[R], mx_b[R], p_even;
+    f32x2 sum2[R];     // packed-math form of (sum_a, sum_b)
+    f32x2 c2, nm2[R];  // {c, c} and {-m, -m}: operands of the packed exponent fma
     bool need;         // tracked pass: lazy-rescale decision for S(t+1)
     unsigned long long t_mid = 0, t_end = 0;   // STAMP builds only
 
@@ -197,9 +199,37 @@ struct WaveCompute {
     template <int E>
     __device__ __forceinline__ void exp_elem(const Scores<R>& cur, float c) {
         constexpr int g = E / (8 * R), r = (E / 8) % R, j = E % 8, e = 8 * g + j;
+        if constexpr (C::PK) {
+            // two adjacent accumulator registers at a time: v_pk_fma_f32, 2 x v_exp_f32, v_pk_add_f32, v_cvt_pk
+            // (5 instead of 7 VALU instructions per pair), all in the slot of the even element
+            if constexpr ((e & 1) == 0) {
+                const f32x2 x = {cur.s[r][e >> 4][e & 15], cur.s[r][e >> 4][(e & 15) + 1]};
+                f32x2 a;   // asm: hipcc splits the vector fma back into two v_fma_f32
+                asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(a) : "v"(x), "v"(c2), "v"(nm2[r]));
+                const f32x2 p = {fast_exp2(a[0]), fast_exp2(a[1])};
+                sum2[r] += p;
+                pw[r][e >> 1] = pack_bf16(p[0], p[1]);
+                asm volatile("" : "+v"(sum2[r]));   // keep the add in this slot
+            }
+            return;
+        }
         const float x = cur.s[r][e >> 4][e & 15];
         const float p = fast_exp2(fmaf(x, c, -m[r]));
-        if constexpr (e & 1) {
+        if constexpr (C::DOT2) {
+            // row sum from the packed bf16 pair: one v_dot2_f32_bf16 (p_lo*1 + p_hi*1 + acc) per two elements
+            // instead of two v_add_f32 -- and it sums exactly the rounded weights the P.V MFMA multiplies
+            if constexpr (e & 1) {
+                pw[r][e >> 1] = pack_bf16(p_even, p);
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                const bf16x2 pp = __builtin_bit_cast(bf16x2, pw[r][e >> 1]);
+                const bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
+                if constexpr ((e >> 1) & 1) sum_b[r] = __builtin_amdgcn_fdot2_f32_bf16(pp, one, sum_b[r], false);
+                else sum_a[r] = __builtin_amdgcn_fdot2_f32_bf16(pp, one, sum_a[r], false);
+                asm volatile("" : "+v"(sum_a[r]), "+v"(sum_b[r]));
+            } else {
+                p_even = p;
+            }
+        } else if constexpr (e & 1) {
             sum_b[r] += p;
             pw[r][e >> 1] = pack_bf16(p_even, p);
             asm volatile("" : "+v"(sum_a[r]), "+v"(sum_b[r]));   // keep the adds in this slot (hipcc sinks them)
@@ -268,7 +298,7 @@ struct WaveCompute {
                 constexpr int v = I - (SA - VPRE);
                 vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DB, v % DB);
             }
-            if constexpr ((I & 1) && (I >> 1) < NL) st.template load<(I >> 1)>(t_load);
+            if constexpr (!C::DBG_NOLOAD && (I & 1) && (I >> 1) < NL) st.template load<(I >> 1)>(t_load);
             if constexpr (!C::VALU_FIRST) exp_slot<I>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
             slots_a<I + 1>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
@@ -313,8 +343,11 @@ struct WaveCompute {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             sum_a[r] = sum_b[r] = 0.f;
+            sum2[r] = f32x2{0.f, 0.f};
+            nm2[r] = f32x2{-m[r], -m[r]};
             mx_a[r] = mx_b[r] = -INFINITY;
         }
+        c2 = f32x2{c, c};
         if constexpr (!C::ASM_MFMA) zero(nxt);   // asm form: the first MFMA of each chain has C = 0
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
@@ -324,7 +357,7 @@ struct WaveCompute {
         slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
 #pragma unroll
-        for (int r = 0; r < R; ++r) l[r] += sum_a[r] + sum_b[r];
+        for (int r = 0; r < R; ++r) l[r] += C::PK ? sum2[r][0] + sum2[r][1] : sum_a[r] + sum_b[r];
         // ONE rescale site: the masked (diagonal / ragged) tile only recomputes the scalar decision and
         // the row max.  (Two sites that both multiply O made hipcc copy all 64 accumulator registers
         // twice per tile on the common path.)

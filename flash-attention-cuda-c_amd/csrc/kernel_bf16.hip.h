@@ -27,8 +27,13 @@
 namespace fa {
 
 template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, bool STAMP_ = false, bool OPTIMISTIC_ = true, int NPRE_ = 4,
-          int VPRE_ = 2, int THR_ = 8, int R_ = 1, bool ASM_MFMA_ = false, bool VALU_FIRST_ = true, bool PERSIST_ = false>
+          int VPRE_ = 2, int THR_ = 8, int R_ = 1, bool ASM_MFMA_ = false, bool VALU_FIRST_ = true, bool PERSIST_ = false,
+          bool PK_ = false, bool DOT2_ = false, bool DBG_NOBAR_ = false, bool DBG_NOLOAD_ = false>
 struct KernelCfg {
+    static constexpr bool DBG_NOLOAD = DBG_NOLOAD_;  // TIMING EXPERIMENT ONLY (wrong results): no global loads in the tile loop
+    static constexpr bool DBG_NOBAR = DBG_NOBAR_;    // TIMING EXPERIMENT ONLY (wrong results): no per-tile barrier
+    static constexpr bool DOT2 = DOT2_;              // row sums by v_dot2_f32_bf16 over the packed weights
+    static constexpr bool PK = PK_;                  // packed-fp32 softmax arithmetic (v_pk_fma_f32 / v_pk_add_f32)
     static constexpr bool PERSIST = PERSIST_;        // one workgroup per CU walks a static list of units (see work_unit)
     static constexpr bool VALU_FIRST = VALU_FIRST_;  // phase-A slots issue their softmax slice before the MFMA
     static constexpr bool ASM_MFMA = ASM_MFMA_;      // inline-asm MFMAs with dictated register classes (for R = 2)
@@ -99,7 +104,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
             st.write_all(smem + so_wr);
         }
         if constexpr (C::STAMP) t4 = cycle_stamp();
-        __syncthreads();
+        if constexpr (!C::DBG_NOBAR) __syncthreads();
         if constexpr (C::STAMP) {
             t6 = cycle_stamp();
             acc[1] += w.t_mid - t0; acc[2] += w.t_end - w.t_mid; acc[3] += t4 - w.t_end; acc[5] += t6 - t4; acc[6] += 1;

@@ -74,8 +74,12 @@ template <int D, bool CAUSAL>
 static std::vector<Variant> make_variants() {
     std::vector<Variant> v;
     v.push_back({"production (persistent, optimistic)", launch_cfg<ProdCfg<D, CAUSAL, __bf16>>});
+    v.push_back({"production + packed fp32 softmax math", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, true>>});
+    v.push_back({"production + dot2 row sums", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, true>>});
+    v.push_back({"EXPERIMENT no per-tile barrier (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, true>>});
+    v.push_back({"EXPERIMENT no global loads in loop (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, false, true>>});
     v.push_back({"one unit per workgroup (r01 a-j)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2>>});
-    v.push_back({"R=2 asm npre4 vpre2 (experimental)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 2, true, true>>});
+    v.push_back({"R=2 asm npre4 vpre2 persistent (experimental)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 2, true, true, true>>});
     v.push_back({"tracked only (persistent)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, false, 4, 2, 8, 1, false, true, true>>});
     v.push_back({"persistent npre6 vpre3", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 6, 3, 8, 1, false, true, true>>});
     v.push_back({"one unit per workgroup STAMP", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, true, true, 4, 2>>});
