@@ -286,14 +286,17 @@ struct WaveCompute {
 
     // ---- the slots -----------------------------------------------------------------------------
     // phase A slot I: fragment f = I/(MPF*R), then (sub, row group) = ((I % (MPF*R)) / R, I % R)
-    template <int I>
+    // LAST: the wave's final tile -- there is no S(t+1) to produce, so the QK^T MFMAs and their K reads are left out
+    template <int I, bool LAST = false>
     __device__ __forceinline__ void slots_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase,
                                             float c, const Scores<R>& cur, Scores<R>& nxt) {
         if constexpr (I < SA) {
             constexpr int f = I / (MPF * R), rem = I % (MPF * R), sub = rem / R, rg = rem % R;
             if constexpr (C::VALU_FIRST) exp_slot<I>(cur, c);   // softmax slice covers the fragment's LDS latency
-            qk_mfma<f, sub, rg>(kf[f % NPRE], nxt);
-            if constexpr (rem == MPF * R - 1 && f + NPRE < NF) kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
+            if constexpr (!LAST) {
+                qk_mfma<f, sub, rg>(kf[f % NPRE], nxt);
+                if constexpr (rem == MPF * R - 1 && f + NPRE < NF) kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
+            }
             if constexpr (I >= SA - VPRE) {   // the last VPRE phase-A slots start the V^T window of phase B
                 constexpr int v = I - (SA - VPRE);
                 vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DB, v % DB);
@@ -301,7 +304,7 @@ struct WaveCompute {
             if constexpr (!C::DBG_NOLOAD && (I & 1) && (I >> 1) < NL) st.template load<(I >> 1)>(t_load);
             if constexpr (!C::VALU_FIRST) exp_slot<I>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
-            slots_a<I + 1>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+            slots_a<I + 1, LAST>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         }
     }
     // phase B slot J: V^T fragment v = J/R (16-key step v/DB, d block v%DB), row group J%R
@@ -331,12 +334,12 @@ struct WaveCompute {
         }
     }
 
-    // One tile: cur = S(t) (consumed), nxt = S(t+1) (produced).  On the wave's last tile (has_next ==
-    // false) the QK^T of the non-existent next tile is still issued -- its result is never looked at --
-    // so that there is ONE hot code path.
+    // One tile: cur = S(t) (consumed), nxt = S(t+1) (produced).  LAST = the wave's last tile: no next tile, so
+    // the step is instantiated without the QK^T MFMAs, their K reads, the max tracking and the rescale
+    // (16 MFMAs per wave and unit that used to run on garbage "so that there is one hot code path").
     // TRACK = true: running row max with lazy rescale (always safe).  TRACK = false: the optimistic
     // pass -- m stays the row max of tile 0 and no max / decision / rescale is issued.
-    template <bool TRACK>
+    template <bool TRACK, bool LAST = false>
     __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
                                               int kbase, int vbase, float c, const Scores<R>& cur, Scores<R>& nxt,
                                               bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
@@ -348,19 +351,22 @@ struct WaveCompute {
             mx_a[r] = mx_b[r] = -INFINITY;
         }
         c2 = f32x2{c, c};
-        if constexpr (!C::ASM_MFMA) zero(nxt);   // asm form: the first MFMA of each chain has C = 0
+        if constexpr (!LAST) {
+            if constexpr (!C::ASM_MFMA) zero(nxt);   // asm form: the first MFMA of each chain has C = 0
 #pragma unroll
-        for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
+            for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        slots_a<0>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        slots_a<0, LAST>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_mid = cycle_stamp();
-        slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
+        slots_b<(TRACK && !LAST), 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
 #pragma unroll
         for (int r = 0; r < R; ++r) l[r] += C::PK ? sum2[r][0] + sum2[r][1] : sum_a[r] + sum_b[r];
         // ONE rescale site: the masked (diagonal / ragged) tile only recomputes the scalar decision and
         // the row max.  (Two sites that both multiply O made hipcc copy all 64 accumulator registers
         // twice per tile on the common path.)
+        if constexpr (LAST) return;
         if (has_next && mask_next) {
             mask(nxt, kv0_next, q_row0, S, lane);
             if constexpr (TRACK) {

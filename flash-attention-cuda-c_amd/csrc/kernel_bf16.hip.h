@@ -28,8 +28,9 @@ namespace fa {
 
 template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, bool STAMP_ = false, bool OPTIMISTIC_ = true, int NPRE_ = 4,
           int VPRE_ = 2, int THR_ = 8, int R_ = 1, bool ASM_MFMA_ = false, bool VALU_FIRST_ = true, bool PERSIST_ = false,
-          bool PK_ = false, bool DOT2_ = false, bool DBG_NOBAR_ = false, bool DBG_NOLOAD_ = false>
+          bool PK_ = false, bool DOT2_ = false, bool DBG_NOBAR_ = false, bool DBG_NOLOAD_ = false, bool SKIP_LAST_QK_ = false>
 struct KernelCfg {
+    static constexpr bool SKIP_LAST_QK = SKIP_LAST_QK_;  // a wave's last tile step runs without the (unused) QK^T MFMAs
     static constexpr bool DBG_NOLOAD = DBG_NOLOAD_;  // TIMING EXPERIMENT ONLY (wrong results): no global loads in the tile loop
     static constexpr bool DBG_NOBAR = DBG_NOBAR_;    // TIMING EXPERIMENT ONLY (wrong results): no per-tile barrier
     static constexpr bool DOT2 = DOT2_;              // row sums by v_dot2_f32_bf16 over the packed weights
@@ -91,15 +92,20 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
     if constexpr (C::STAMP) { tp2 = cycle_stamp(); acc[8] += tp1 - tp0; acc[9] += tp2 - tp1; }
 
     int so_cur = 0, so_nxt = SLOT, so_wr = 2 * SLOT;   // ring slot byte offsets of tiles t, t+1, t+2
-    auto step = [&](int t, Scores<C::R>& cur, Scores<C::R>& nxt) {
+    // kind: 0 = full step (a next tile exists), 1 = the wave's last tile (no QK^T), 2 = staging only (the wave is
+    // past its causal diagonal but still stages its share of the tiles the other waves need)
+    auto step = [&](int t, int kind, Scores<C::R>& cur, Scores<C::R>& nxt) {
         unsigned long long t0 = 0, t4 = 0, t6 = 0;
         if constexpr (C::STAMP) t0 = cycle_stamp();
-        if (t < my_tiles) {
-            const bool has_next = t + 1 < my_tiles;
+        if (kind == 0 || (kind == 1 && !C::SKIP_LAST_QK)) {
+            const bool has_next = kind == 0;
             w.template tile_step<TRACK>(st, t + 2, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
                                         has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
+        } else if (kind == 1) {
+            if constexpr (C::SKIP_LAST_QK)
+                w.template tile_step<TRACK, true>(st, t + 2, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur,
+                                                  nxt, false, false, 0, q_row0, S, lane);
         } else {
-            // wave already past its causal diagonal: it still stages its share of the tile
             st.load_all(t + 2);
             st.write_all(smem + so_wr);
         }
@@ -107,16 +113,33 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
         if constexpr (!C::DBG_NOBAR) __syncthreads();
         if constexpr (C::STAMP) {
             t6 = cycle_stamp();
-            acc[1] += w.t_mid - t0; acc[2] += w.t_end - w.t_mid; acc[3] += t4 - w.t_end; acc[5] += t6 - t4; acc[6] += 1;
+            if (kind != 2) { acc[1] += w.t_mid - t0; acc[2] += w.t_end - w.t_mid; acc[3] += t4 - w.t_end; acc[6] += 1; }
+            acc[5] += t6 - t4;
         }
         const int tmp = so_cur;
         so_cur = so_nxt;
         so_nxt = so_wr;
         so_wr = tmp;
     };
-    for (int t = 0; t < n_tiles; t += 2) {
-        step(t, sA, sB);
-        if (t + 1 < n_tiles) step(t + 1, sB, sA);
+    if constexpr (C::SKIP_LAST_QK) {
+        // full steps in ping-pong pairs, then ONE instance of the last-tile step (always on sA: an odd count of
+        // full steps copies sB over once per unit), then the staging-only steps.  Every wave runs n_tiles steps.
+        const int n_full = my_tiles > 0 ? my_tiles - 1 : 0;
+        int t = 0;
+        while (t < n_full) {
+            step(t, 0, sA, sB);
+            ++t;
+            if (t < n_full) { step(t, 0, sB, sA); ++t; }
+            else sA = sB;
+        }
+        if (my_tiles > 0) { step(t, 1, sA, sB); ++t; }
+        for (; t < n_tiles; ++t) step(t, 2, sA, sB);
+    } else {
+        auto kind_of = [&](int t) { return t + 1 < my_tiles ? 0 : (t < my_tiles ? 1 : 2); };
+        for (int t = 0; t < n_tiles; t += 2) {
+            step(t, kind_of(t), sA, sB);
+            if (t + 1 < n_tiles) step(t + 1, kind_of(t + 1), sB, sA);
+        }
     }
     if constexpr (TRACK) return false;
     else {

@@ -75,6 +75,7 @@ static std::vector<Variant> make_variants() {
     std::vector<Variant> v;
     v.push_back({"production (persistent, optimistic)", launch_cfg<ProdCfg<D, CAUSAL, __bf16>>});
     v.push_back({"production + packed fp32 softmax math", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, true>>});
+    v.push_back({"production + last step without QK", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, false, false, true>>});
     v.push_back({"production + dot2 row sums", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, true>>});
     v.push_back({"EXPERIMENT no per-tile barrier (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, true>>});
     v.push_back({"EXPERIMENT no global loads in loop (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, false, true>>});
