@@ -87,7 +87,7 @@ static int device_cus() {
 
 static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_dtype, float scale,
                      fa_launch_plan* plan) {
-    (void)causal; (void)o_dtype;
+    (void)causal;
     const bool mfma_bf16 = dtype == FA_DTYPE_BF16 && (d == 64 || d == 128) && scale > 0.f;
     const bool mfma_fp8 = dtype == FA_DTYPE_FP8_E4M3 && d == 128 && scale > 0.f;
     const bool mfma_f32 = dtype == FA_DTYPE_F32 && (d == 64 || d == 128) && scale > 0.f;
@@ -107,6 +107,7 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
         plan->threads = 512;
         // 3-slot ring of [K image (input type) | V image (bf16)]
         plan->lds_bytes = 3 * plan->kv_block_rows * d * ((mfma_fp8 ? 1 : 2) + 2);
+        if (o_dtype == FA_DTYPE_F32 && plan->lds_bytes < 65536) plan->lds_bytes = 65536;   // fp32 epilogue staging (d = 64)
         // persistent grid: one workgroup per CU (8 XCD groups x CUs/8), each walking ceil(units/grid) units;
         // with fewer units than CUs, one workgroup per unit
         const int nQ = getNumCta(S, plan->q_block_rows);
@@ -125,12 +126,24 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
     return FA_OK;
 }
 
-// The MFMA kernel needs up to 96 KiB of dynamic LDS: above the 64 KiB default, so the limit is raised
-// once per instantiation (function-local static: thread-safe, not a stream operation).
+// The MFMA kernels need up to 96 KiB of dynamic LDS: above the 64 KiB default, so the limit is raised once
+// per (kernel instantiation, device) -- function attributes are per device, and the multi-GPU driver calls
+// in from one host thread per device.  Not a stream operation; a repeated set is harmless.
+template <typename Kernel>
+static hipError_t raise_lds_limit(Kernel kernel, int bytes, std::atomic<bool> (&done)[64]) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
+    return e;
+}
+
 template <class Cfg>
 static hipError_t launch_mfma(const Params& p, const fa_launch_plan& plan, hipStream_t st) {
-    static const hipError_t attr = hipFuncSetAttribute((const void*)fwd_mfma_kernel<Cfg>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    static std::atomic<bool> done[64];
+    const hipError_t attr = raise_lds_limit(fwd_mfma_kernel<Cfg>, Cfg::LDS_BYTES, done);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((fwd_mfma_kernel<Cfg>), dim3(plan.grid), dim3(plan.threads), Cfg::LDS_BYTES, st, p);
     return hipGetLastError();
@@ -145,8 +158,8 @@ static hipError_t launch_mfma_out(const Params& p, const fa_launch_plan& plan, i
 
 template <class Cfg>
 static hipError_t launch_f32(const Params& p, const fa_launch_plan& plan, hipStream_t st) {
-    static const hipError_t attr = hipFuncSetAttribute((const void*)fwd_f32_mfma_kernel<Cfg>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    static std::atomic<bool> done[64];
+    const hipError_t attr = raise_lds_limit(fwd_f32_mfma_kernel<Cfg>, Cfg::LDS_BYTES, done);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((fwd_f32_mfma_kernel<Cfg>), dim3(plan.grid), dim3(plan.threads), Cfg::LDS_BYTES, st, p);
     return hipGetLastError();
@@ -162,10 +175,17 @@ static hipError_t launch_f32_out(const Params& p, const fa_launch_plan& plan, in
 template <typename InT, typename OutT>
 static hipError_t launch_generic_io(const Params& p, const fa_launch_plan& plan, int d, bool causal, hipStream_t st) {
     dim3 grid(plan.grid), block(plan.threads);
-    if (causal)
+    static std::atomic<bool> done_c[64], done_n[64];
+    const int lds_max = generic_lds_bytes(256);   // 100 KiB at the largest supported head dimension
+    if (causal) {
+        const hipError_t attr = raise_lds_limit(fwd_generic_kernel<InT, OutT, true>, lds_max, done_c);
+        if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL((fwd_generic_kernel<InT, OutT, true>), grid, block, plan.lds_bytes, st, p, d);
-    else
+    } else {
+        const hipError_t attr = raise_lds_limit(fwd_generic_kernel<InT, OutT, false>, lds_max, done_n);
+        if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL((fwd_generic_kernel<InT, OutT, false>), grid, block, plan.lds_bytes, st, p, d);
+    }
     return hipGetLastError();
 }
 
@@ -276,10 +296,19 @@ int flash_attention_weights(const void* Q, const void* K, const float* LSE, floa
     const int64_t blocks = (int64_t)batchSize * numHeads * p.nQ * p.nK;
     if (blocks > INT32_MAX) return FA_ERR_BAD_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int lds = weights_lds_bytes(dHead);
-    if (dtype == FA_DTYPE_F32) hipLaunchKernelGGL((attn_weights_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, st, p);
-    else if (dtype == FA_DTYPE_BF16) hipLaunchKernelGGL((attn_weights_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((attn_weights_kernel<fp8_t>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    const int lds = weights_lds_bytes(dHead), lds_max = weights_lds_bytes(256);   // 80 KiB at dHead = 256
+    static std::atomic<bool> done[3][64];
+    hipError_t attr;
+    if (dtype == FA_DTYPE_F32) {
+        if ((attr = raise_lds_limit(attn_weights_kernel<float>, lds_max, done[0])) != hipSuccess) return (int)attr;
+        hipLaunchKernelGGL((attn_weights_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    } else if (dtype == FA_DTYPE_BF16) {
+        if ((attr = raise_lds_limit(attn_weights_kernel<__bf16>, lds_max, done[1])) != hipSuccess) return (int)attr;
+        hipLaunchKernelGGL((attn_weights_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    } else {
+        if ((attr = raise_lds_limit(attn_weights_kernel<fp8_t>, lds_max, done[2])) != hipSuccess) return (int)attr;
+        hipLaunchKernelGGL((attn_weights_kernel<fp8_t>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    }
     return (int)hipGetLastError();
 }
 

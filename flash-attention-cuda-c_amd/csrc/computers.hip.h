@@ -492,6 +492,48 @@ struct WaveCompute {
             if (row0 + row < S) *reinterpret_cast<u32x4*>(Oh + (int64_t)(row0 + row) * oS_bytes + cc * 16) = v;
         }
     }
+    // 4-byte outputs through LDS, 64 columns at a time: O^T accumulators -> this wave's private region as a
+    // row-major [32R rows][64 floats] half tile (ds_write_b128, 16-byte chunk c of row q at chunk c ^ (q & 15):
+    // the 8 lanes of a write group hit 8 different chunk columns) -> 256 contiguous bytes of a row per 16 lanes
+    // back out.  The direct form (store_o) writes 32-byte pieces of 32 different rows per instruction.
+    // `region` = 32*R*256 bytes private to this wave; the caller guarantees the K/V ring is dead.
+    template <typename OutT>
+    __device__ __forceinline__ void store_o_lds32(lds_ptr region, char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S,
+                                                  int lane) {
+        static_assert(sizeof(OutT) == 4, "for fp32 outputs");
+        const int q = lane & 31, h = lane >> 5;
+        if constexpr (C::ASM_MFMA) mfma_drain();
+        float inv[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float l_tot = sum_both_halves(l[r]);
+            store_lse(lse_head, l_tot, r, row0 + 32 * r, S, lane);
+            inv[r] = 1.0f / l_tot;
+        }
+        const int rr = lane >> 4, cc = lane & 15;
+#pragma unroll
+        for (int hf = 0; hf < D / 64; ++hf) {
+            if (hf > 0) __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's reads of the previous half are done
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int db = 2 * hf + dd, cidx = 8 * dd + 2 * g4 + h;
+                        const f32x4 v = {o[r][db][4 * g4 + 0] * inv[r], o[r][db][4 * g4 + 1] * inv[r],
+                                         o[r][db][4 * g4 + 2] * inv[r], o[r][db][4 * g4 + 3] * inv[r]};
+                        *reinterpret_cast<FA_LDS f32x4*>(region + (32 * r + q) * 256 + (((cidx ^ q) & 15) << 4)) = v;
+                    }
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): only this wave's own ds_writes have to land
+#pragma unroll
+            for (int i = 0; i < 8 * R; ++i) {
+                const int row = 4 * i + rr;
+                const f32x4 v = *reinterpret_cast<FA_LDS const f32x4*>(region + row * 256 + (((cc ^ row) & 15) << 4));
+                if (row0 + row < S) *reinterpret_cast<f32x4*>(Oh + (int64_t)(row0 + row) * oS_bytes + hf * 256 + cc * 16) = v;
+            }
+        }
+    }
 };
 
 }  // namespace fa

@@ -28,8 +28,9 @@ namespace fa {
 
 template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, bool STAMP_ = false, bool OPTIMISTIC_ = true, int NPRE_ = 4,
           int VPRE_ = 2, int THR_ = 8, int R_ = 1, bool ASM_MFMA_ = false, bool VALU_FIRST_ = true, bool PERSIST_ = false,
-          bool PK_ = false, bool DOT2_ = false, bool DBG_NOBAR_ = false, bool DBG_NOLOAD_ = false, bool SKIP_LAST_QK_ = false>
+          bool PK_ = false, bool DOT2_ = false, bool DBG_NOBAR_ = false, bool DBG_NOLOAD_ = false, bool SKIP_LAST_QK_ = false, bool LDS_EPILOGUE32_ = false>
 struct KernelCfg {
+    static constexpr bool LDS_EPILOGUE32 = LDS_EPILOGUE32_;  // fp32 outputs leave through LDS as whole 256-byte row pieces
     static constexpr bool SKIP_LAST_QK = SKIP_LAST_QK_;  // a wave's last tile step runs without the (unused) QK^T MFMAs
     static constexpr bool DBG_NOLOAD = DBG_NOLOAD_;  // TIMING EXPERIMENT ONLY (wrong results): no global loads in the tile loop
     static constexpr bool DBG_NOBAR = DBG_NOBAR_;    // TIMING EXPERIMENT ONLY (wrong results): no per-tile barrier
@@ -49,12 +50,14 @@ struct KernelCfg {
     static constexpr int NPRE = NPRE_;               // K fragments in flight ahead of their MFMA
     static constexpr int VPRE = VPRE_;               // V^T fragments in flight ahead of their MFMA
     static constexpr int THR = THR_;                 // lazy-rescale threshold of the tracked pass, log2 units
-    static constexpr int LDS_BYTES = 3 * TileGeom<D_, ESZ_>::SLOT;
+    static constexpr int RING_BYTES = 3 * TileGeom<D_, ESZ_>::SLOT;
+    // the fp32 LDS epilogue stages 256 rows x 64 floats: more than the ring at d = 64 (or with fp8 K images)
+    static constexpr int LDS_BYTES = (LDS_EPILOGUE32_ && sizeof(OutT_) == 4 && RING_BYTES < 65536) ? 65536 : RING_BYTES;
 };
 
-// What the library launches: optimistic pass, VALU-first slots, persistent grid.
+// What the library launches: optimistic pass, VALU-first slots, persistent grid, LDS epilogues for every output type.
 template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false>
-using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, STAMP, true, 4, 2, 8, 1, false, true, true>;
+using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, STAMP, true, 4, 2, 8, 1, false, true, true, false, false, false, false, false, true>;
 
 // One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the
 // result has to be recomputed with max tracking (only ever true for TRACK = false).
@@ -266,13 +269,17 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
             static_assert(256 * D * 2 <= C::LDS_BYTES, "epilogue regions must fit the ring");
             if (cur.wave_live)
                 w.template store_o_lds<OutT>(smem + wave * (WROWS * D * 2), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e);
+        } else if constexpr (C::LDS_EPILOGUE32) {
+            static_assert(256 * 64 * 4 <= C::LDS_BYTES, "epilogue regions must fit the ring");
+            if (cur.wave_live)
+                w.template store_o_lds32<OutT>(smem + wave * (WROWS * 256), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e);
         } else {
             if (cur.wave_live) w.template store_o<OutT>(cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e);
         }
         if constexpr (C::STAMP) acc[4] += cycle_stamp() - t_ep0;   // epilogue: normalise + store O (issue side)
         if (!more) break;
         // the next prologue overwrites ring slots that other waves' epilogue regions alias
-        if constexpr (sizeof(OutT) == 2) __syncthreads();
+        if constexpr (sizeof(OutT) == 2 || C::LDS_EPILOGUE32) __syncthreads();
         cur = nxt;
     }
     if constexpr (C::STAMP) {

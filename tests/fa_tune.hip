@@ -50,6 +50,7 @@ static int g_cus = 256, g_jpx = 0;   // --jpx N: workgroups per XCD group of the
 struct Variant {
     std::string name;
     std::function<void(const Params&, int grid)> launch;
+    int osz = 2;   // bytes per output element (2: bf16, 4: fp32)
 };
 
 template <class K>
@@ -76,6 +77,8 @@ static std::vector<Variant> make_variants() {
     v.push_back({"production (persistent, optimistic)", launch_cfg<ProdCfg<D, CAUSAL, __bf16>>});
     v.push_back({"production + packed fp32 softmax math", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, true>>});
     v.push_back({"production + last step without QK", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, false, false, true>>});
+    v.push_back({"fp32 O, direct epilogue", launch_cfg<KernelCfg<D, CAUSAL, float, 2, false, true, 4, 2, 8, 1, false, true, true>>, 4});
+    v.push_back({"fp32 O, LDS epilogue (production)", launch_cfg<ProdCfg<D, CAUSAL, float>>, 4});
     v.push_back({"production + dot2 row sums", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, true>>});
     v.push_back({"EXPERIMENT no per-tile barrier (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, true>>});
     v.push_back({"EXPERIMENT no global loads in loop (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, false, true>>});
@@ -116,7 +119,7 @@ int main(int argc, char** argv) {
     fill_randn_bf16(hq, 1, qkscale); fill_randn_bf16(hk, 2, qkscale); fill_randn_bf16(hv, 3);
     void *dq, *dk, *dv, *dref, *dout;
     HIP_CHECK(hipMalloc(&dq, n * 2)); HIP_CHECK(hipMalloc(&dk, n * 2)); HIP_CHECK(hipMalloc(&dv, n * 2));
-    HIP_CHECK(hipMalloc(&dref, n * 2)); HIP_CHECK(hipMalloc(&dout, n * 2));
+    HIP_CHECK(hipMalloc(&dref, n * 2)); HIP_CHECK(hipMalloc(&dout, n * 4));   // room for fp32-output variants
     for (int t = 0; t < 3; ++t) {
         char* dst = (char*)(t == 0 ? dq : t == 1 ? dk : dv);
         const std::vector<uint16_t>& src = t == 0 ? hq : t == 1 ? hk : hv;
@@ -161,13 +164,19 @@ int main(int argc, char** argv) {
         }
     };
     std::vector<uint16_t> out0(n), outv(n);
+    std::vector<float> outf(n);
     printf("problem: B=%d H=%d S=%d d=%d causal=%d  grid=%d  rounds=%d qkscale=%g jpx=%d\n", B, H, S, d, causal, grid, rounds, qkscale, g_jpx);
     for (size_t vi = 0; vi < vars.size(); ++vi) {
-        HIP_CHECK(hipMemset(dout, 0xff, n * 2));
+        HIP_CHECK(hipMemset(dout, 0xff, n * 4));
         vars[vi].launch(p, grid);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());
-        HIP_CHECK(hipMemcpy(outv.data(), dout, n * 2, hipMemcpyDeviceToHost));
+        if (vars[vi].osz == 4) {   // fp32 output: round to bf16 on the host so the comparisons below stay uniform
+            HIP_CHECK(hipMemcpy(outf.data(), dout, n * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n; ++i) outv[i] = oracle_f32_to_bf16(outf[i]);
+        } else {
+            HIP_CHECK(hipMemcpy(outv.data(), dout, n * 2, hipMemcpyDeviceToHost));
+        }
         double max_err = 0;
         size_t bad = 0;
         for (int g : {0, BH - 1}) {

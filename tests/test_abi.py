@@ -87,7 +87,7 @@ def test_launch_plan(B, H, S, d, causal, dtype, kid, br, bc):
         assert p["grid"] == 8 * (-(-units // 8)) and p["grid"] >= units
     assert p["threads"] % 64 == 0 and p["lds_bytes"] <= 160 * 1024
     if kid == 1:
-        assert p["lds_bytes"] == 3 * 2 * 64 * d * 2      # 3-slot ring of K+V tiles
+        assert p["lds_bytes"] == max(3 * 2 * 64 * d * 2, 65536)   # 3-slot ring of K+V tiles; >= the fp32 epilogue's 64 KiB
     if kid == 2:
         assert p["lds_bytes"] == 3 * 64 * d * 3          # fp8 K image + bf16 V image
 

@@ -112,6 +112,18 @@ def test_attn_matrix_causal_and_rectangular():
             assert (P.cpu().numpy()[..., np.triu(np.ones((Sq, Sk), dtype=bool), 1)] == 0).all()
 
 
+def test_attn_matrix_largest_head_dim():
+    """dHead = 256: the generic forward kernel and the weights kernel both take > 64 KiB of dynamic LDS."""
+    B, H, S, d = 1, 2, 150, 256
+    Q, K, V = (randn((B, H, S, d), s, torch.float32) for s in (53, 54, 55))
+    O, lse = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=True, return_lse=True)
+    P = fa.attention_weights(Q.to(DEV), K.to(DEV), lse, is_causal=True)
+    torch.cuda.synchronize()
+    check(O.cpu().numpy(), oracle.attention(Q.numpy(), K.numpy(), V.numpy(), causal=True), 2e-5, 1e-4)
+    np.testing.assert_allclose(P.sum(-1).cpu().numpy(), 1.0, atol=2e-5)
+    check(torch.matmul(P, V.to(DEV)).cpu().numpy(), O.cpu().numpy(), 2e-5, 1e-4)
+
+
 # ------------------------------------------------------------------ golden vectors (from check.py)
 @pytest.mark.parametrize("name", ["F0", "F3", "F4", "F6"])
 def test_golden_fp32_through_checkpy_api(golden, name):
