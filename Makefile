@@ -9,6 +9,8 @@ KHDR     := $(wildcard $(PKG)/csrc/*.h) $(PKG)/helpers.hpp include/flash_attenti
 
 all: $(LIB) oracle $(PKG)/fa_main tests/fa_test tests/fa_tune tests/micro/simd_mix tests/micro/valu_rates
 
+lib: $(LIB)
+
 $(LIB): $(KSRC) $(KHDR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KSRC)
 
@@ -41,4 +43,4 @@ asm: $(KSRC) $(KHDR)
 clean:
 	rm -f $(LIB) $(PKG)/fa_main tests/fa_test tests/fa_tune tests/micro/simd_mix tests/micro/valu_rates oracle/liboracle_attention.so
 	rm -rf build
-.PHONY: all oracle clean asm
+.PHONY: all lib oracle clean asm

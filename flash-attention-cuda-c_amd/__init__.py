@@ -27,7 +27,8 @@ LIB_PATH = os.path.join(_HERE, "libflash_attention.so")
 FA_DTYPE_F32, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3, FA_DTYPE_F16 = 0, 1, 2, 3
 
 # every symbol include/flash_attention.h declares
-EXPORTS = ("flash_attention", "flash_attention_strided", "flash_attention_lse", "flash_attention_cross", "flash_attention_weights", "flash_attention_plan",
+EXPORTS = ("flash_attention", "flash_attention_strided", "flash_attention_lse", "flash_attention_cross", "flash_attention_weights", "flash_attention_shard_range", "flash_attention_sharded",
+           "flash_attention_plan",
            "flash_attention_error_string", "flash_attention_version")
 
 
@@ -70,6 +71,11 @@ def lib() -> ctypes.CDLL:
         L.flash_attention_cross.restype = i
         L.flash_attention_weights.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, b, i, sp, sp, vp]
         L.flash_attention_weights.restype = i
+        ip, pp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p)
+        L.flash_attention_shard_range.argtypes = [i, i, i, ip, ip]
+        L.flash_attention_shard_range.restype = i
+        L.flash_attention_sharded.argtypes = [i, ip, pp, pp, pp, pp, i, i, i, i, f, b, i, i, pp]
+        L.flash_attention_sharded.restype = i
         L.flash_attention_plan.argtypes = [i, i, i, i, b, i, i, ctypes.POINTER(FaLaunchPlan)]
         L.flash_attention_plan.restype = i
         L.flash_attention_error_string.argtypes = [i]
@@ -176,6 +182,28 @@ def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None
                                                  *common, *refs, _stream_ptr(stream))
     _check(rc)
     return (O, lse) if return_lse else O
+
+
+def shard_range(total_heads, rank, world):
+    """[lo, hi) of flattened heads g = b*H + h owned by `rank` of `world` (C ABI twin of shard.shard_heads)."""
+    lo, hi = ctypes.c_int(), ctypes.c_int()
+    _check(lib().flash_attention_shard_range(total_heads, rank, world, ctypes.byref(lo), ctypes.byref(hi)))
+    return lo.value, hi.value
+
+
+def flash_attention_sharded(Qs, Ks, Vs, Os, batchSize, numHeads, scale=None, is_causal=False, streams=None):
+    """One host thread, several devices: Qs[r], Ks[r], Vs[r], Os[r] are rank r's dense [hi-lo, S, d] slabs of the
+    flattened heads (shard_range), each resident on its own device.  No collective; asynchronous."""
+    n = len(Qs)
+    S, d = Qs[0].shape[-2:]
+    if scale is None:
+        scale = 1.0 / float(d) ** 0.5
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    devs = (ctypes.c_int * n)(*[t.device.index for t in Qs])
+    st = (ctypes.c_void_p * n)(*[s.cuda_stream if s is not None else None for s in (streams or [None] * n)])
+    _check(lib().flash_attention_sharded(n, devs, arr(Qs), arr(Ks), arr(Vs), arr(Os), batchSize, numHeads, S, d, float(scale),
+                                         bool(is_causal), _dtype_code(Qs[0].dtype), _dtype_code(Os[0].dtype), st))
+    return Os
 
 
 def attention_weights(Q, K, lse, scale=None, is_causal=False, stream=None):

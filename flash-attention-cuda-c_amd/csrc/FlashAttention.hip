@@ -312,6 +312,36 @@ int flash_attention_weights(const void* Q, const void* K, const float* LSE, floa
     return (int)hipGetLastError();
 }
 
+int flash_attention_shard_range(int totalHeads, int rank, int nRanks, int* lo, int* hi) {
+    if (!lo || !hi) return FA_ERR_NULL_POINTER;
+    if (totalHeads < 0 || nRanks <= 0 || rank < 0 || rank >= nRanks) return FA_ERR_BAD_SHAPE;
+    *lo = (int)(((int64_t)totalHeads * rank) / nRanks);
+    *hi = (int)(((int64_t)totalHeads * (rank + 1)) / nRanks);
+    return FA_OK;
+}
+
+int flash_attention_sharded(int nDevices, const int* deviceIds, const void* const* Q, const void* const* K,
+                            const void* const* V, void* const* O, int batchSize, int numHeads, int seqLen, int dHead,
+                            float scale, bool is_causal, int dtype, int o_dtype, void* const* streams) {
+    if (!deviceIds || !Q || !K || !V || !O) return FA_ERR_NULL_POINTER;
+    if (nDevices <= 0 || batchSize <= 0 || numHeads <= 0 || (int64_t)batchSize * numHeads > INT32_MAX / 2) return FA_ERR_BAD_SHAPE;
+    int home = 0;
+    hipError_t e = hipGetDevice(&home);
+    if (e != hipSuccess) return (int)e;
+    int rc = FA_OK;
+    for (int r = 0; r < nDevices && rc == FA_OK; ++r) {
+        int lo = 0, hi = 0;
+        flash_attention_shard_range(batchSize * numHeads, r, nDevices, &lo, &hi);
+        if (hi == lo) continue;                       // more devices than heads: nothing for this one
+        if ((e = hipSetDevice(deviceIds[r])) != hipSuccess) { rc = (int)e; break; }
+        // the slab is a [hi-lo, 1, seqLen, dHead] problem of its own
+        rc = fa::run(Q[r], K[r], V[r], O[r], nullptr, hi - lo, 1, seqLen, seqLen, dHead, scale, is_causal, dtype, o_dtype,
+                     nullptr, nullptr, nullptr, nullptr, streams ? streams[r] : nullptr);
+    }
+    (void)hipSetDevice(home);
+    return rc;
+}
+
 int flash_attention_plan(int batchSize, int numHeads, int seqLen, int dHead, bool is_causal, int dtype,
                          int o_dtype, fa_launch_plan* plan) {
     if (!plan) return FA_ERR_NULL_POINTER;

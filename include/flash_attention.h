@@ -149,6 +149,26 @@ int flash_attention_weights(const void* Q, const void* K, const float* LSE, floa
                             const fa_strides* sQ, const fa_strides* sK, void* stream);
 
 /*
+ * Multi-GPU: every (b,h) pair is an independent problem, so the forward pass shards
+ * over the flattened head index g = b*numHeads + h with no data-path collective.
+ *
+ * flash_attention_shard_range -- rank `rank` of `nRanks` owns heads [*lo, *hi): contiguous ranges that tile
+ * [0, totalHeads) exactly, sizes differing by at most one.  Returns 0 or FA_ERR_BAD_SHAPE.
+ *
+ * flash_attention_sharded -- one host thread drives nDevices devices: device deviceIds[r] holds, as its own
+ * dense [hi-lo, seqLen, dHead] slabs Q[r], K[r], V[r], O[r], the head range of rank r, and gets the same
+ * kernel enqueued on streams[r] (NULL array or NULL entry = that device's default stream).  Asynchronous
+ * like flash_attention(); the caller's current device is restored.  Returns the first error, else 0.
+ * (One process per GPU -- bench.py under torchrun -- just calls flash_attention() on its own slab.)
+ */
+int flash_attention_shard_range(int totalHeads, int rank, int nRanks, int* lo, int* hi);
+
+int flash_attention_sharded(int nDevices, const int* deviceIds,
+                            const void* const* Q, const void* const* K, const void* const* V, void* const* O,
+                            int batchSize, int numHeads, int seqLen, int dHead,
+                            float scale, bool is_causal, int dtype, int o_dtype, void* const* streams);
+
+/*
  * Launch-geometry policy -- the counterpart of the reference's helpers.hpp:8-36
  * (calculateSizeBlockQ / calculateSizeBlockKV / getNumCta, which return constants there).
  * Fills the tile sizes and grid the library will use for this problem; returns 0 or FA_ERR_*.

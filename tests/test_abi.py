@@ -97,3 +97,18 @@ def test_no_cpu_fallback_in_binding():
     x = torch.zeros(1, 1, 16, 16)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         fa.flash_attention(x, x, x)
+
+
+def test_shard_range_matches_the_python_partition():
+    """flash_attention_shard_range (C ABI) == shard.shard_heads: contiguous, exhaustive, sizes within one."""
+    from flash_attention_cuda_c_amd import shard
+    for total in (0, 1, 7, 128, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            ranges = [fa.shard_range(total, r, world) for r in range(world)]
+            assert ranges == [shard.shard_heads(total, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            sizes = [hi - lo for lo, hi in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(fa.FlashAttentionError):
+        fa.shard_range(8, 3, 2)
