@@ -121,13 +121,18 @@ struct WaveCompute {
     __device__ __forceinline__ u32x4 k_read(lds_ptr kimg, int kbase, int f) const {
         return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + (f % FPH) * 2048 + (f / FPH) * 512));
     }
-    // QK^T MFMA of fragment f, sub-step sub (fp8 only), row group r
+    // QK^T MFMA of fragment f, sub-step sub (fp8 only), row group r.  kprev = the fragment before kfrag (MX form only).
     template <int F, int SUB, int RG>
-    __device__ __forceinline__ void qk_mfma(const u32x4& kfrag, Scores<R>& n) const {
+    __device__ __forceinline__ void qk_mfma(const u32x4& kprev, const u32x4& kfrag, Scores<R>& n) const {
         const u32x4& q = qf[RG][F % FPH];
         f32x16& acc = n.s[RG][F / FPH];
         constexpr bool first = (F % FPH == 0) && SUB == 0;   // first MFMA of this accumulation chain
-        if constexpr (C::ASM_MFMA) {
+        if constexpr (C::MXQK) {
+            // fragments (F-1, F) = 64 contraction elements in ONE block-scaled MFMA, issued in the last slot of
+            // the pair; the pair's other three slots carry only their softmax slice
+            static_assert(ESZ == 1 && !C::ASM_MFMA, "the MX form is for fp8 inputs");
+            if constexpr ((F & 1) && SUB == MPF - 1) acc = mfma_32x32x64_fp8_unit_scale(kprev, kfrag, qf[RG][(F - 1) % FPH], q, acc);
+        } else if constexpr (C::ASM_MFMA) {
             if constexpr (ESZ == 2) {
                 mfma_qk_asm<first>(acc, kfrag, q);
             } else {
@@ -156,8 +161,8 @@ struct WaveCompute {
         if constexpr (I == 0 && !C::ASM_MFMA) zero(n);
         if constexpr (I < SA) {
             constexpr int f = I / (MPF * R), sub = (I % (MPF * R)) / R, rg = I % R;
-            if constexpr (I % (MPF * R) == 0) kf[0] = k_read(kimg, kbase, f);
-            qk_mfma<f, sub, rg>(kf[0], n);
+            if constexpr (I % (MPF * R) == 0) kf[f % 2] = k_read(kimg, kbase, f);
+            qk_mfma<f, sub, rg>(kf[(f + 1) % 2], kf[f % 2], n);
             qk_all<I + 1>(kimg, kbase, n);
         }
     }
@@ -294,8 +299,16 @@ struct WaveCompute {
             constexpr int f = I / (MPF * R), rem = I % (MPF * R), sub = rem / R, rg = rem % R;
             if constexpr (C::VALU_FIRST) exp_slot<I>(cur, c);   // softmax slice covers the fragment's LDS latency
             if constexpr (!LAST) {
-                qk_mfma<f, sub, rg>(kf[f % NPRE], nxt);
-                if constexpr (rem == MPF * R - 1 && f + NPRE < NF) kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
+                qk_mfma<f, sub, rg>(kf[(f + NPRE - 1) % NPRE], kf[f % NPRE], nxt);
+                if constexpr (C::MXQK) {
+                    // both fragments of a pair stay live until the pair's MFMA: refill the two window entries after it
+                    if constexpr (rem == MPF * R - 1 && (f & 1)) {
+                        if constexpr (f - 1 + NPRE < NF) kf[(f - 1) % NPRE] = k_read(k_next, kbase, f - 1 + NPRE);
+                        if constexpr (f + NPRE < NF) kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
+                    }
+                } else if constexpr (rem == MPF * R - 1 && f + NPRE < NF) {
+                    kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
+                }
             }
             if constexpr (I >= SA - VPRE) {   // the last VPRE phase-A slots start the V^T window of phase B
                 constexpr int v = I - (SA - VPRE);

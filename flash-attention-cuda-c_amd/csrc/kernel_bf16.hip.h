@@ -28,8 +28,9 @@ namespace fa {
 
 template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, bool STAMP_ = false, bool OPTIMISTIC_ = true, int NPRE_ = 4,
           int VPRE_ = 2, int THR_ = 8, int R_ = 1, bool ASM_MFMA_ = false, bool VALU_FIRST_ = true, bool PERSIST_ = false,
-          bool PK_ = false, bool DOT2_ = false, bool DBG_NOBAR_ = false, bool DBG_NOLOAD_ = false, bool SKIP_LAST_QK_ = false, bool LDS_EPILOGUE32_ = false>
+          bool PK_ = false, bool DOT2_ = false, bool DBG_NOBAR_ = false, bool DBG_NOLOAD_ = false, bool SKIP_LAST_QK_ = false, bool LDS_EPILOGUE32_ = false, bool MXQK_ = false>
 struct KernelCfg {
+    static constexpr bool MXQK = MXQK_;              // fp8 inputs: QK^T on the block-scaled 32x32x64 MFMA (unit scales), 2x rate
     static constexpr bool LDS_EPILOGUE32 = LDS_EPILOGUE32_;  // fp32 outputs leave through LDS as whole 256-byte row pieces
     static constexpr bool SKIP_LAST_QK = SKIP_LAST_QK_;  // a wave's last tile step runs without the (unused) QK^T MFMAs
     static constexpr bool DBG_NOLOAD = DBG_NOLOAD_;  // TIMING EXPERIMENT ONLY (wrong results): no global loads in the tile loop
@@ -55,9 +56,10 @@ struct KernelCfg {
     static constexpr int LDS_BYTES = (LDS_EPILOGUE32_ && sizeof(OutT_) == 4 && RING_BYTES < 65536) ? 65536 : RING_BYTES;
 };
 
-// What the library launches: optimistic pass, VALU-first slots, persistent grid, LDS epilogues for every output type.
+// What the library launches: optimistic pass, VALU-first slots, persistent grid, LDS epilogues for every output type,
+// and for fp8 inputs QK^T on the block-scaled (MX) 32x32x64 MFMA with unit scales.
 template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false>
-using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, STAMP, true, 4, 2, 8, 1, false, true, true, false, false, false, false, false, true>;
+using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, STAMP, true, 4, 2, 8, 1, false, true, true, false, false, false, false, false, true, (ESZ == 1)>;
 
 // One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the
 // result has to be recomputed with max tracking (only ever true for TRACK = false).

@@ -91,8 +91,17 @@ static std::vector<Variant> make_variants() {
     return v;
 }
 
+template <bool CAUSAL>
+static std::vector<Variant> make_variants_fp8() {
+    std::vector<Variant> v;
+    v.push_back({"fp8 production (MX: QK^T on 32x32x64 f8f6f4, unit scales)", launch_cfg<ProdCfg<128, CAUSAL, __bf16, 1>>});
+    v.push_back({"fp8 QK^T on the non-scaled 32x32x16 fp8 MFMA", launch_cfg<KernelCfg<128, CAUSAL, __bf16, 1, false, true, 4, 2, 8, 1, false, true, true, false, false, false, false, false, true, false>>});
+    return v;
+}
+
 int main(int argc, char** argv) {
     int B = 8, H = 16, S = 4096, d = 128, causal = 0, rounds = 7;
+    bool fp8 = false;
     double qkscale = 1.0;   // multiplies Q and K: 12 makes later tiles exceed the tile-0 row max by > 2^127 (fallback path)
     std::vector<int> only;
     std::vector<int> pos;
@@ -101,6 +110,7 @@ int main(int argc, char** argv) {
         if (a == "--rounds" && i + 1 < argc) rounds = atoi(argv[++i]);
         else if (a == "--qkscale" && i + 1 < argc) qkscale = atof(argv[++i]);
         else if (a == "--jpx" && i + 1 < argc) g_jpx = atoi(argv[++i]);
+        else if (a == "--fp8") fp8 = true;   // OCP e4m3fn inputs (d = 128): the fp8 kernel variants
         else if (a == "--only" && i + 1 < argc) {
             char* s = argv[++i];
             for (char* t = strtok(s, ","); t; t = strtok(nullptr, ",")) only.push_back(atoi(t));
@@ -117,15 +127,25 @@ int main(int argc, char** argv) {
     const int distinct = std::min(BH, 8);
     std::vector<uint16_t> hq(per_head * distinct), hk(per_head * distinct), hv(per_head * distinct);
     fill_randn_bf16(hq, 1, qkscale); fill_randn_bf16(hk, 2, qkscale); fill_randn_bf16(hv, 3);
+    const int esz = fp8 ? 1 : 2;
+    std::vector<uint8_t> eq, ek, ev;
+    if (fp8) {   // round the bf16 draws to e4m3fn; the host copies (hq..) keep the rounded values as bf16 (exact)
+        eq.resize(hq.size()); ek.resize(hk.size()); ev.resize(hv.size());
+        for (size_t i = 0; i < hq.size(); ++i) {
+            eq[i] = oracle_f32_to_e4m3fn(oracle_bf16_to_f32(hq[i])); hq[i] = oracle_f32_to_bf16(oracle_e4m3fn_to_f32(eq[i]));
+            ek[i] = oracle_f32_to_e4m3fn(oracle_bf16_to_f32(hk[i])); hk[i] = oracle_f32_to_bf16(oracle_e4m3fn_to_f32(ek[i]));
+            ev[i] = oracle_f32_to_e4m3fn(oracle_bf16_to_f32(hv[i])); hv[i] = oracle_f32_to_bf16(oracle_e4m3fn_to_f32(ev[i]));
+        }
+    }
     void *dq, *dk, *dv, *dref, *dout;
     HIP_CHECK(hipMalloc(&dq, n * 2)); HIP_CHECK(hipMalloc(&dk, n * 2)); HIP_CHECK(hipMalloc(&dv, n * 2));
     HIP_CHECK(hipMalloc(&dref, n * 2)); HIP_CHECK(hipMalloc(&dout, n * 4));   // room for fp32-output variants
     for (int t = 0; t < 3; ++t) {
         char* dst = (char*)(t == 0 ? dq : t == 1 ? dk : dv);
-        const std::vector<uint16_t>& src = t == 0 ? hq : t == 1 ? hk : hv;
+        const void* src = fp8 ? (const void*)(t == 0 ? eq : t == 1 ? ek : ev).data() : (const void*)(t == 0 ? hq : t == 1 ? hk : hv).data();
         for (int g = 0; g < BH; g += distinct) {
             const int cnt = std::min(distinct, BH - g);
-            HIP_CHECK(hipMemcpy(dst + (size_t)g * per_head * 2, src.data(), per_head * cnt * 2, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(dst + (size_t)g * per_head * esz, src, per_head * cnt * esz, hipMemcpyHostToDevice));
         }
     }
     Params p{};
@@ -146,7 +166,9 @@ int main(int argc, char** argv) {
     p.dbg = ddbg;
 
     std::vector<Variant> vars;
-    if (d == 128) vars = causal ? make_variants<128, true>() : make_variants<128, false>();
+    if (fp8 && d == 128) vars = causal ? make_variants_fp8<true>() : make_variants_fp8<false>();
+    else if (fp8) { fprintf(stderr, "--fp8 needs d = 128\n"); return 2; }
+    else if (d == 128) vars = causal ? make_variants<128, true>() : make_variants<128, false>();
     else if (d == 64) vars = causal ? make_variants<64, true>() : make_variants<64, false>();
     else { fprintf(stderr, "d must be 64 or 128\n"); return 2; }
     if (!only.empty()) {
