@@ -257,6 +257,21 @@ int main(int argc, char** argv) {
                 }
                 if (n > 0) printf("      wave %d: phase A %.0f  phase B %.0f  barrier wait %.0f\n", wv, a / n, b / n, bar / n);
             }
+            {   // spread of workgroup lifetimes (wave 0 of each): a static schedule ends with its slowest workgroup
+                double mn = 1e30, mx = 0, sum = 0; int cnt = 0;
+                double xsum[8] = {0}; int xcnt[8] = {0};
+                for (size_t g = 0; g < (size_t)grid; ++g) {
+                    const double life = (double)h[(g * 8) * 16 + 0];
+                    if (life <= 0) continue;
+                    mn = std::min(mn, life); mx = std::max(mx, life); sum += life; ++cnt;
+                    xsum[g & 7] += life; ++xcnt[g & 7];
+                }
+                if (cnt > 0) {
+                    printf("    workgroup lifetimes (%d workgroups): min %.0f  mean %.0f  max %.0f cycles  (max/mean %.3f); per XCD mean:", cnt, mn, sum / cnt, mx, mx / (sum / cnt));
+                    for (int x = 0; x < 8; ++x) printf(" %.0f", xcnt[x] ? xsum[x] / xcnt[x] : 0.0);
+                    printf("\n");
+                }
+            }
             const double loop = (seg[1] + seg[2] + seg[3] + seg[5]) / nw, tot = seg[0] / nw;
             printf("    per workgroup-wave (%.0f waves): lifetime %.0f = Q load+pin %.0f | stage tiles 0,1 + barrier %.0f | QK(0)+max %.0f | tile loop %.0f (%.1f%%) | finite check %.0f | epilogue %.0f | unaccounted %.0f\n",
                    nw, tot, seg[7] / nw, seg[8] / nw, seg[9] / nw, loop, 100 * loop / tot, seg[10] / nw, seg[4] / nw,

@@ -391,6 +391,45 @@ def test_sharded_entry_point_single_device():
     assert torch.equal(torch.cat(Os), flat(full))
 
 
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        dtype = [torch.bfloat16, torch.float32, "fp8"][int(rng.integers(0, 3))]
+        d = 128 if dtype == "fp8" else int(rng.choice([64, 128, 128, 32, 80, 256] if dtype == torch.float32 else [64, 128, 128, 80]))
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 6))
+        Sq = int(rng.choice([1, 7, 63, 64, 65, 200, 256, 257, 511, 700, 1030]))
+        Sk = Sq if rng.random() < 0.6 else int(rng.choice([1, 5, 64, 129, 300, 1000]))
+        cases.append((i, dtype, B, H, Sq, Sk, d, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)),
+                      [torch.float32, torch.bfloat16][int(rng.integers(0, 2))]))
+    return cases
+
+
+@pytest.mark.parametrize("i,dtype,B,H,Sq,Sk,d,causal,strided,out_dtype", _fuzz_cases(36, 2024))
+def test_fuzz_shapes_layouts_dtypes(i, dtype, B, H, Sq, Sk, d, causal, strided, out_dtype):
+    """Seeded sweep over (dtype, B, H, Sq, Sk, d, causal, model-layout strides, output dtype): every dispatch
+    branch (bf16 / fp8 / fp32 MFMA kernels, generic kernel, LDS and direct epilogues, cross lengths, ragged
+    tails) against the float64 oracle on the same rounded inputs."""
+    if dtype == "fp8":
+        if FP8 is None:
+            pytest.skip("torch build without float8_e4m3fn")
+        dtype = FP8
+    mk = lambda S, seed: randn((B, S, H * d), seed, torch.float32).to(dtype)         # (B, S, H*d) model layout
+    Qm, Km, Vm = mk(Sq, 1000 + 3 * i), mk(Sk, 1001 + 3 * i), mk(Sk, 1002 + 3 * i)
+    view = lambda t, S: t.view(B, S, H, d).transpose(1, 2)                            # [B, H, S, d] strided view
+    Qd, Kd, Vd = view(Qm.to(DEV), Sq), view(Km.to(DEV), Sk), view(Vm.to(DEV), Sk)
+    if not strided:
+        Qd, Kd, Vd = Qd.contiguous(), Kd.contiguous(), Vd.contiguous()
+    O, lse = fa.flash_attention(Qd, Kd, Vd, is_causal=causal, out_dtype=out_dtype, return_lse=True)
+    torch.cuda.synchronize()
+    f = lambda t, S: view(t, S).float().numpy()
+    ref = oracle.attention_numpy(f(Qm, Sq), f(Km, Sk), f(Vm, Sk), causal=causal)
+    atol, rtol = tol_for(torch.float32 if dtype == torch.float32 else torch.bfloat16, out_dtype)
+    check(O.float().cpu().numpy(), ref, atol, rtol)
+    np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(f(Qm, Sq), f(Km, Sk), causal=causal), rtol=2e-6,
+                               atol=2e-4 if dtype == torch.float32 else 3e-3)
+
+
 def test_heads_are_independent():
     """Reference defect D2 (every query attends to every batch/head) must not be reproduced:
     a head computed alone equals the same head computed inside a batch, bit for bit."""
