@@ -28,13 +28,18 @@ namespace fa {
 
 template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, bool STAMP_ = false, bool OPTIMISTIC_ = true, int NPRE_ = 4,
           int VPRE_ = 2, int THR_ = 8, int R_ = 1, bool ASM_MFMA_ = false, bool VALU_FIRST_ = true, bool PERSIST_ = false,
-          bool PK_ = false, bool DOT2_ = false, bool DBG_NOBAR_ = false, bool DBG_NOLOAD_ = false, bool SKIP_LAST_QK_ = false, bool LDS_EPILOGUE32_ = false, bool MXQK_ = false>
+          bool PK_ = false, bool DOT2_ = false, bool DBG_NOBAR_ = false, bool DBG_NOLOAD_ = false, bool SKIP_LAST_QK_ = false, bool LDS_EPILOGUE32_ = false, bool MXQK_ = false, int DBG_ = 0>
 struct KernelCfg {
     static constexpr bool MXQK = MXQK_;              // fp8 inputs: QK^T on the block-scaled 32x32x64 MFMA (unit scales), 2x rate
     static constexpr bool LDS_EPILOGUE32 = LDS_EPILOGUE32_;  // fp32 outputs leave through LDS as whole 256-byte row pieces
     static constexpr bool SKIP_LAST_QK = SKIP_LAST_QK_;  // a wave's last tile step runs without the (unused) QK^T MFMAs
-    static constexpr bool DBG_NOLOAD = DBG_NOLOAD_;  // TIMING EXPERIMENT ONLY (wrong results): no global loads in the tile loop
-    static constexpr bool DBG_NOBAR = DBG_NOBAR_;    // TIMING EXPERIMENT ONLY (wrong results): no per-tile barrier
+    // TIMING EXPERIMENTS ONLY (wrong results by construction; tests/fa_tune): which dependency costs what.
+    static constexpr int DBG = DBG_ | (DBG_NOBAR_ ? 1 : 0) | (DBG_NOLOAD_ ? 2 : 0);
+    static constexpr bool DBG_NOBAR = DBG & 1;     // no per-tile barrier
+    static constexpr bool DBG_NOLOAD = DBG & 2;    // no global loads in the tile loop
+    static constexpr bool DBG_PCONST = DBG & 4;    // P.V MFMAs take a constant B operand (exp / pack still run): no VALU -> MFMA dependency
+    static constexpr bool DBG_SCONST = DBG & 8;    // the exponentials read constants, not the score accumulators: no MFMA -> VALU dependency
+    static constexpr bool DBG_KVCONST = DBG & 16;  // MFMA A operands are constants; the LDS reads still run and are consumed once per phase
     static constexpr bool DOT2 = DOT2_;              // row sums by v_dot2_f32_bf16 over the packed weights
     static constexpr bool PK = PK_;                  // packed-fp32 softmax arithmetic (v_pk_fma_f32 / v_pk_add_f32)
     static constexpr bool PERSIST = PERSIST_;        // one workgroup per CU walks a static list of units (see work_unit)

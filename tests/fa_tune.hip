@@ -70,6 +70,10 @@ static void launch_cfg(const Params& p, int grid) {
     }
 }
 
+// production configuration + a bit mask of timing-only experiments (KernelCfg::DBG)
+template <int D, bool CAUSAL, int DBG>
+using DbgCfg = KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, false, false, false, true, false, DBG>;
+
 // KernelCfg<D, CAUSAL, OutT, ESZ, STAMP, OPTIMISTIC, NPRE, VPRE, THR>
 template <int D, bool CAUSAL>
 static std::vector<Variant> make_variants() {
@@ -80,8 +84,13 @@ static std::vector<Variant> make_variants() {
     v.push_back({"fp32 O, direct epilogue", launch_cfg<KernelCfg<D, CAUSAL, float, 2, false, true, 4, 2, 8, 1, false, true, true>>, 4});
     v.push_back({"fp32 O, LDS epilogue (production)", launch_cfg<ProdCfg<D, CAUSAL, float>>, 4});
     v.push_back({"production + dot2 row sums", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, true>>});
-    v.push_back({"EXPERIMENT no per-tile barrier (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, true>>});
-    v.push_back({"EXPERIMENT no global loads in loop (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, false, true>>});
+    v.push_back({"EXPERIMENT no per-tile barrier (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 1>>});
+    v.push_back({"EXPERIMENT no global loads in loop (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 2>>});
+    v.push_back({"EXPERIMENT P.V takes constant P (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 4>>});
+    v.push_back({"EXPERIMENT exps read constants (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 8>>});
+    v.push_back({"EXPERIMENT MFMA A operands constant (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 16>>});
+    v.push_back({"EXPERIMENT P const + exps const + A const (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 28>>});
+    v.push_back({"EXPERIMENT all of the above (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 31>>});
     v.push_back({"one unit per workgroup (r01 a-j)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2>>});
     v.push_back({"R=2 asm npre4 vpre2 persistent (experimental)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 2, true, true, true>>});
     v.push_back({"tracked only (persistent)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, false, 4, 2, 8, 1, false, true, true>>});
