@@ -158,12 +158,17 @@ static Result run_case(const Case& c, bool perf, int iters) {
         for (int i = 0; i < 3; ++i)
             flash_attention(dq, dk, dv, dout, c.B, c.H, c.S, c.d, scale, c.causal != 0, c.dtype, c.o_dtype, nullptr);
         std::vector<float> ms(iters);
+        // batches of REPS back-to-back launches per event pair: a launch that starts from an idle, down-clocked GPU
+        // (one sync per launch) reads 10-20 % slow
+        constexpr int REPS = 5;
         for (int i = 0; i < iters; ++i) {
             HIP_CHECK(hipEventRecord(e0, nullptr));
-            flash_attention(dq, dk, dv, dout, c.B, c.H, c.S, c.d, scale, c.causal != 0, c.dtype, c.o_dtype, nullptr);
+            for (int k = 0; k < REPS; ++k)
+                flash_attention(dq, dk, dv, dout, c.B, c.H, c.S, c.d, scale, c.causal != 0, c.dtype, c.o_dtype, nullptr);
             HIP_CHECK(hipEventRecord(e1, nullptr));
             HIP_CHECK(hipEventSynchronize(e1));
             HIP_CHECK(hipEventElapsedTime(&ms[i], e0, e1));
+            ms[i] /= REPS;
         }
         std::sort(ms.begin(), ms.end());
         r.ms_med = ms[iters / 2]; r.ms_min = ms[0];
