@@ -4,15 +4,15 @@
 // kernels/computers.cuh:33-67 / kernels/loaders.cuh:132-156,177-201.  The reference commits a tile and
 // immediately waits for it on every cuda::pipeline (no load/compute overlap).
 //
-// One workgroup = 256 query rows of one (batch, head) = 8/R waves, a wave owning R groups of 32 rows.
-// R = 1 (8 waves, two per SIMD) is what the library launches.  R = 2 (4 waves, one per SIMD with the whole
-// 512-entry register file, every K / V^T fragment read feeding two MFMAs, inline-asm MFMAs that pin Q and
-// O in AGPRs) is an experimental arm kept for tests/fa_tune: measured +2 % non-causal, -3 % causal against
-// R = 1 (profiles/r01_tune_r1q_*.log), so it is not dispatched.  KV tiles of 64 keys live in a 3-slot LDS
-// ring [K image | V image] (loaders.hip.h).  Iteration t of a wave reads
+// One workgroup = 8 waves (two per SIMD, <= 256 VGPRs) processes UNITS of 256 query rows of one (batch, head), a
+// wave owning 32 rows.  The grid is persistent: one workgroup per CU walks a static, balanced list of units
+// (work_unit) and requests the next unit's Q and KV tile 0 before it runs the current unit's epilogue.
+// KV tiles of 64 keys live in a 3-slot LDS ring [K image | V image] (loaders.hip.h).  Iteration t of a wave reads
 // K(t+1) and V(t) and stages tile t+2 into slot (t+2)%3 = slot (t-1)%3, last read in iteration t-1, which
 // every wave left at the previous barrier: ONE barrier per tile.  The loop is unrolled x2 with ping-pong
 // score registers so S(t+1) never has to be copied into S(t).  What happens inside a tile: computers.hip.h.
+// Tuning decisions and the measured alternatives (64 rows per wave, one unit per workgroup, ...) are the
+// fields of fa::Opt below.
 //
 // Optimistic max.  exp2 / bf16 / f32 accumulation have ~2^127 of headroom, so the first pass takes
 // every exponential relative to the row max of tile 0 and issues no per-tile max, decision or rescale
@@ -26,45 +26,53 @@
 
 namespace fa {
 
-template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, bool STAMP_ = false, bool OPTIMISTIC_ = true, int NPRE_ = 4,
-          int VPRE_ = 2, int THR_ = 8, int R_ = 1, bool ASM_MFMA_ = false, bool VALU_FIRST_ = true, bool PERSIST_ = false,
-          bool PK_ = false, bool DOT2_ = false, bool DBG_NOBAR_ = false, bool DBG_NOLOAD_ = false, bool SKIP_LAST_QK_ = false, bool LDS_EPILOGUE32_ = false, bool MXQK_ = false, int DBG_ = 0>
+// Everything about the kernel that is a tuning decision rather than part of the problem.  The defaults ARE the
+// production configuration; tests/fa_tune instantiates the alternatives with designated initialisers, e.g.
+// KernelCfg<128, true, __bf16, 2, Opt{.persist = false}>.  What each rejected alternative measured: DESIGN.md section 4.
+struct Opt {
+    bool stamp = false;          // diagnostic build: s_memtime stamps around the segments (tests/fa_tune)
+    bool optimistic = true;      // optimistic pass + finiteness check + tracked fallback (false: tracked pass only)
+    int npre = 4;                // K fragments in flight ahead of their MFMA
+    int vpre = 2;                // V^T fragments in flight ahead of their MFMA
+    int thr = 8;                 // lazy-rescale threshold of the tracked pass, log2 units
+    int r = 1;                   // 32-row query groups per wave: 1 = 8 waves, two per SIMD; 2 = 4 waves (experimental arm)
+    bool asm_mfma = false;       // inline-asm MFMAs with dictated register classes (needed by r = 2)
+    bool valu_first = true;      // phase-A slots issue their softmax slice before the MFMA
+    bool persist = true;         // one workgroup per CU walks a static list of units (see work_unit)
+    bool lds_epilogue32 = true;  // fp32 outputs leave through LDS as whole 256-byte row pieces
+    int mxqk = -1;               // fp8 inputs: QK^T on the block-scaled 32x32x64 MFMA with unit scales (-1: on iff fp8)
+    // rejected by measurement, kept as arms of the tuner
+    bool pk = false;             // packed-fp32 softmax arithmetic (v_pk_fma_f32 / v_pk_add_f32): -10 %
+    bool dot2 = false;           // row sums by v_dot2_f32_bf16 over the packed weights: -3 %
+    bool skip_last_qk = false;   // a wave's last tile step without the (unused) QK^T MFMAs: -1..2 %
+    // TIMING EXPERIMENTS ONLY (wrong results by construction): bit 0 no per-tile barrier, bit 1 no global loads in the
+    // tile loop, bit 2 P.V takes a constant P (no VALU -> MFMA dependency)
+    int dbg = 0;
+};
+
+template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, Opt O = Opt{}>
 struct KernelCfg {
-    static constexpr bool MXQK = MXQK_;              // fp8 inputs: QK^T on the block-scaled 32x32x64 MFMA (unit scales), 2x rate
-    static constexpr bool LDS_EPILOGUE32 = LDS_EPILOGUE32_;  // fp32 outputs leave through LDS as whole 256-byte row pieces
-    static constexpr bool SKIP_LAST_QK = SKIP_LAST_QK_;  // a wave's last tile step runs without the (unused) QK^T MFMAs
-    // TIMING EXPERIMENTS ONLY (wrong results by construction; tests/fa_tune): which dependency costs what.
-    static constexpr int DBG = DBG_ | (DBG_NOBAR_ ? 1 : 0) | (DBG_NOLOAD_ ? 2 : 0);
-    static constexpr bool DBG_NOBAR = DBG & 1;     // no per-tile barrier
-    static constexpr bool DBG_NOLOAD = DBG & 2;    // no global loads in the tile loop
-    static constexpr bool DBG_PCONST = DBG & 4;    // P.V MFMAs take a constant B operand (exp / pack still run): no VALU -> MFMA dependency
-    static constexpr bool DBG_SCONST = DBG & 8;    // the exponentials read constants, not the score accumulators: no MFMA -> VALU dependency
-    static constexpr bool DBG_KVCONST = DBG & 16;  // MFMA A operands are constants; the LDS reads still run and are consumed once per phase
-    static constexpr bool DOT2 = DOT2_;              // row sums by v_dot2_f32_bf16 over the packed weights
-    static constexpr bool PK = PK_;                  // packed-fp32 softmax arithmetic (v_pk_fma_f32 / v_pk_add_f32)
-    static constexpr bool PERSIST = PERSIST_;        // one workgroup per CU walks a static list of units (see work_unit)
-    static constexpr bool VALU_FIRST = VALU_FIRST_;  // phase-A slots issue their softmax slice before the MFMA
-    static constexpr bool ASM_MFMA = ASM_MFMA_;      // inline-asm MFMAs with dictated register classes (for R = 2)
     static constexpr int D = D_;
-    static constexpr int R = R_;                     // 32-row query groups per wave (1 or 2)
-    static constexpr int NWAVES = 8 / R_;            // waves per workgroup (256 query rows)
     static constexpr bool CAUSAL = CAUSAL_;
     using OutT = OutT_;
     static constexpr int ESZ = ESZ_;                 // bytes per Q/K/V element: 2 = bf16, 1 = fp8 e4m3fn
-    static constexpr bool STAMP = STAMP_;            // diagnostic build: s_memtime stamps around the segments
-    static constexpr bool OPTIMISTIC = OPTIMISTIC_;  // optimistic pass + finiteness check + tracked fallback
-    static constexpr int NPRE = NPRE_;               // K fragments in flight ahead of their MFMA
-    static constexpr int VPRE = VPRE_;               // V^T fragments in flight ahead of their MFMA
-    static constexpr int THR = THR_;                 // lazy-rescale threshold of the tracked pass, log2 units
+    static constexpr bool STAMP = O.stamp, OPTIMISTIC = O.optimistic, ASM_MFMA = O.asm_mfma, VALU_FIRST = O.valu_first;
+    static constexpr bool PERSIST = O.persist, LDS_EPILOGUE32 = O.lds_epilogue32, PK = O.pk, DOT2 = O.dot2;
+    static constexpr bool SKIP_LAST_QK = O.skip_last_qk;
+    static constexpr bool MXQK = O.mxqk < 0 ? ESZ_ == 1 : O.mxqk != 0;
+    static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr;
+    static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
+    static constexpr int NWAVES = 8 / O.r;           // waves per workgroup (256 query rows)
+    static constexpr int DBG = O.dbg;
+    static constexpr bool DBG_NOBAR = DBG & 1, DBG_NOLOAD = DBG & 2, DBG_PCONST = DBG & 4;
     static constexpr int RING_BYTES = 3 * TileGeom<D_, ESZ_>::SLOT;
-    // the fp32 LDS epilogue stages 256 rows x 64 floats: more than the ring at d = 64 (or with fp8 K images)
-    static constexpr int LDS_BYTES = (LDS_EPILOGUE32_ && sizeof(OutT_) == 4 && RING_BYTES < 65536) ? 65536 : RING_BYTES;
+    // the fp32 LDS epilogue stages 256 rows x 64 floats: more than the ring at d = 64
+    static constexpr int LDS_BYTES = (O.lds_epilogue32 && sizeof(OutT_) == 4 && RING_BYTES < 65536) ? 65536 : RING_BYTES;
 };
 
-// What the library launches: optimistic pass, VALU-first slots, persistent grid, LDS epilogues for every output type,
-// and for fp8 inputs QK^T on the block-scaled (MX) 32x32x64 MFMA with unit scales.
+// What the library launches: the defaults of Opt.
 template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false>
-using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, STAMP, true, 4, 2, 8, 1, false, true, true, false, false, false, false, false, true, (ESZ == 1)>;
+using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, Opt{.stamp = STAMP}>;
 
 // One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the
 // result has to be recomputed with max tracking (only ever true for TRACK = false).

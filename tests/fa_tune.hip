@@ -70,33 +70,28 @@ static void launch_cfg(const Params& p, int grid) {
     }
 }
 
-// production configuration + a bit mask of timing-only experiments (KernelCfg::DBG)
-template <int D, bool CAUSAL, int DBG>
-using DbgCfg = KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, false, false, false, true, false, DBG>;
-
-// KernelCfg<D, CAUSAL, OutT, ESZ, STAMP, OPTIMISTIC, NPRE, VPRE, THR>
+// Every variant is the production configuration (fa::Opt's defaults) with the named fields changed.
 template <int D, bool CAUSAL>
 static std::vector<Variant> make_variants() {
+    using T = __bf16;
     std::vector<Variant> v;
-    v.push_back({"production (persistent, optimistic)", launch_cfg<ProdCfg<D, CAUSAL, __bf16>>});
-    v.push_back({"production + packed fp32 softmax math", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, true>>});
-    v.push_back({"production + last step without QK", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, false, false, false, true>>});
-    v.push_back({"fp32 O, direct epilogue", launch_cfg<KernelCfg<D, CAUSAL, float, 2, false, true, 4, 2, 8, 1, false, true, true>>, 4});
+    v.push_back({"production (persistent, optimistic)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
+    v.push_back({"production + packed fp32 softmax math", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.pk = true}>>});
+    v.push_back({"production + last step without QK", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.skip_last_qk = true}>>});
+    v.push_back({"fp32 O, direct epilogue", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.lds_epilogue32 = false}>>, 4});
     v.push_back({"fp32 O, LDS epilogue (production)", launch_cfg<ProdCfg<D, CAUSAL, float>>, 4});
-    v.push_back({"production + dot2 row sums", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 1, false, true, true, false, true>>});
-    v.push_back({"EXPERIMENT no per-tile barrier (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 1>>});
-    v.push_back({"EXPERIMENT no global loads in loop (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 2>>});
-    v.push_back({"EXPERIMENT P.V takes constant P (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 4>>});
-    v.push_back({"EXPERIMENT exps read constants (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 8>>});
-    v.push_back({"EXPERIMENT MFMA A operands constant (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 16>>});
-    v.push_back({"EXPERIMENT P const + exps const + A const (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 28>>});
-    v.push_back({"EXPERIMENT all of the above (wrong O)", launch_cfg<DbgCfg<D, CAUSAL, 31>>});
-    v.push_back({"one unit per workgroup (r01 a-j)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2>>});
-    v.push_back({"R=2 asm npre4 vpre2 persistent (experimental)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 4, 2, 8, 2, true, true, true>>});
-    v.push_back({"tracked only (persistent)", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, false, 4, 2, 8, 1, false, true, true>>});
-    v.push_back({"persistent npre6 vpre3", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, false, true, 6, 3, 8, 1, false, true, true>>});
-    v.push_back({"one unit per workgroup STAMP", launch_cfg<KernelCfg<D, CAUSAL, __bf16, 2, true, true, 4, 2>>});
-    v.push_back({"production STAMP", launch_cfg<ProdCfg<D, CAUSAL, __bf16, 2, true>>});
+    v.push_back({"production + dot2 row sums", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dot2 = true}>>});
+    v.push_back({"EXPERIMENT no per-tile barrier (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 1}>>});
+    v.push_back({"EXPERIMENT no global loads in loop (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 2}>>});
+    v.push_back({"EXPERIMENT P.V takes constant P (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 4}>>});
+    v.push_back({"EXPERIMENT no barrier + no loads + constant P (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 7}>>});
+    v.push_back({"one unit per workgroup (r01 a-j)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.persist = false}>>});
+    v.push_back({"R=2 asm persistent (experimental)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.r = 2, .asm_mfma = true}>>});
+    v.push_back({"tracked only (persistent)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.optimistic = false}>>});
+    v.push_back({"persistent npre6 vpre3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3}>>});
+    v.push_back({"MFMA-first slots (old order)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = false}>>});
+    v.push_back({"one unit per workgroup STAMP", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.stamp = true, .persist = false}>>});
+    v.push_back({"production STAMP", launch_cfg<ProdCfg<D, CAUSAL, T, 2, true>>});
     return v;
 }
 
@@ -104,7 +99,7 @@ template <bool CAUSAL>
 static std::vector<Variant> make_variants_fp8() {
     std::vector<Variant> v;
     v.push_back({"fp8 production (MX: QK^T on 32x32x64 f8f6f4, unit scales)", launch_cfg<ProdCfg<128, CAUSAL, __bf16, 1>>});
-    v.push_back({"fp8 QK^T on the non-scaled 32x32x16 fp8 MFMA", launch_cfg<KernelCfg<128, CAUSAL, __bf16, 1, false, true, 4, 2, 8, 1, false, true, true, false, false, false, false, false, true, false>>});
+    v.push_back({"fp8 QK^T on the non-scaled 32x32x16 fp8 MFMA", launch_cfg<KernelCfg<128, CAUSAL, __bf16, 1, Opt{.mxqk = 0}>>});
     return v;
 }
 
