@@ -107,6 +107,44 @@ struct WaveCompute {
             for (int u = 0; u < FPH; ++u) qf[r][u] = *reinterpret_cast<const u32x4*>(src + u * 32);
         }
     }
+    // Coalesced form (Opt::coalesced_q).  load_q above has every lane read 16-byte pieces of its own row: one
+    // instruction touches 32 rows x 2 pieces, 64 separate 16-byte requests.  Here instruction i fetches 64/CH WHOLE
+    // rows (CH = 16-byte chunks per row; lane = (row, chunk)), and the fragments are formed by one trip through
+    // this wave's private LDS region: chunk c of row q is parked at chunk c ^ (q & (CH-1)), so the 16 rows of a
+    // ds_read_b128 lane group land on different banks.  Same instruction count, a quarter of the memory requests.
+    static constexpr int QCH = (D * ESZ) / 16;     // 16-byte chunks per Q row
+    static constexpr int QRPI = 64 / QCH;          // rows fetched per instruction
+    static_assert(32 / QRPI == FPH, "coalesced Q: as many loads as fragments");
+    __device__ __forceinline__ void load_q_rows(const char* Qh, int64_t qS_bytes, int row0, int S, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < FPH; ++i) {
+                int row = row0 + 32 * r + i * QRPI + lane / QCH;
+                row = row < S ? row : S - 1;
+                qf[r][i] = *reinterpret_cast<const u32x4*>(Qh + row * qS_bytes + (lane % QCH) * 16);
+            }
+    }
+    // region: 32*R rows x D*ESZ bytes private to this wave, not aliased by anything live (kernel_bf16.hip.h)
+    __device__ __forceinline__ void q_rows_to_fragments(lds_ptr region, int lane) {
+        constexpr int ROWB = D * ESZ;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < FPH; ++i) {
+                const int q = 32 * r + i * QRPI + lane / QCH, c = lane % QCH;
+                lds_write_b128(region, q * ROWB + (((c ^ q) & (QCH - 1)) << 4), qf[r][i]);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own writes only: LDS executes a wave's accesses in order
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int u = 0; u < FPH; ++u) {
+                const int q = 32 * r + (lane & 31), c = 2 * u + (lane >> 5);
+                qf[r][u] = __builtin_bit_cast(u32x4, lds_read_b128(region, q * ROWB + (((c ^ q) & (QCH - 1)) << 4)));
+            }
+    }
+
     // Make the Q fragments look "consumed" so hipcc waits for their loads HERE and not with a
     // pessimistic vmcnt inside the main loop (where it would also drain the tile prefetch).
     __device__ __forceinline__ void pin_q() {

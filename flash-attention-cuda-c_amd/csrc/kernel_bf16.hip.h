@@ -40,6 +40,7 @@ struct Opt {
     bool valu_first = true;      // phase-A slots issue their softmax slice before the MFMA
     bool persist = true;         // one workgroup per CU walks a static list of units (see work_unit)
     bool lds_epilogue32 = true;  // fp32 outputs leave through LDS as whole 256-byte row pieces
+    bool coalesced_q = false;    // Q rows fetched whole and turned into fragments through LDS (see q_rows_to_fragments)
     int mxqk = -1;               // fp8 inputs: QK^T on the block-scaled 32x32x64 MFMA with unit scales (-1: on iff fp8)
     // rejected by measurement, kept as arms of the tuner
     bool pk = false;             // packed-fp32 softmax arithmetic (v_pk_fma_f32 / v_pk_add_f32): -10 %
@@ -59,6 +60,7 @@ struct KernelCfg {
     static constexpr bool STAMP = O.stamp, OPTIMISTIC = O.optimistic, ASM_MFMA = O.asm_mfma, VALU_FIRST = O.valu_first;
     static constexpr bool PERSIST = O.persist, LDS_EPILOGUE32 = O.lds_epilogue32, PK = O.pk, DOT2 = O.dot2;
     static constexpr bool SKIP_LAST_QK = O.skip_last_qk;
+    static constexpr bool COALESCED_Q = O.coalesced_q && O.r == 1;
     static constexpr bool MXQK = O.mxqk < 0 ? ESZ_ == 1 : O.mxqk != 0;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
@@ -242,13 +244,24 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
     typename WaveCompute<C>::Stage st;
     st.init(cur.Kh, cur.Vh, kSb, vSb, Sk, wave, lane);
     st.load_all(0);                                 // tile 0 and Q travel together (one HBM round trip)
-    w.load_q(cur.Qh, qSb, cur.q_row0, S, lane);
+    if constexpr (C::COALESCED_Q) w.load_q_rows(cur.Qh, qSb, cur.q_row0, S, lane);
+    else w.load_q(cur.Qh, qSb, cur.q_row0, S, lane);
     unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     while (true) {
         unsigned long long t_q0 = 0;
         if constexpr (C::STAMP) t_q0 = cycle_stamp();
         w.pin_q();
+        if constexpr (C::COALESCED_Q) {
+            // staging regions sit behind ring slot 0 (tile 0 is about to be written there by other waves); every
+            // wave finishes this round trip before the first barrier of the pass, after which slot 1 is written
+            using G = TileGeom<D, ESZ>;
+            static_assert(G::SLOT + 256 * D * ESZ <= C::LDS_BYTES, "Q staging regions must fit behind slot 0");
+            int lane_q = lane;   // keep the 16 staging addresses inside the unit loop (hoisted, they spill)
+            if constexpr (C::PERSIST) asm volatile("" : "+v"(lane_q));
+            w.q_rows_to_fragments(smem + G::SLOT + wave * (WROWS * D * ESZ), lane_q);
+            w.pin_q();
+        }
         if constexpr (C::STAMP) acc[7] += cycle_stamp() - t_q0;
 
         if constexpr (C::OPTIMISTIC) {
@@ -268,7 +281,8 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
                 nxt.set(p, g, qb, wave);
                 st.init(nxt.Kh, nxt.Vh, kSb, vSb, Sk, wave, lane);
                 st.load_all(0);
-                w.load_q(nxt.Qh, qSb, nxt.q_row0, S, lane);
+                if constexpr (C::COALESCED_Q) w.load_q_rows(nxt.Qh, qSb, nxt.q_row0, S, lane);
+                else w.load_q(nxt.Qh, qSb, nxt.q_row0, S, lane);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

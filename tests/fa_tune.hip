@@ -76,6 +76,7 @@ static std::vector<Variant> make_variants() {
     using T = __bf16;
     std::vector<Variant> v;
     v.push_back({"production (persistent, optimistic)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
+    v.push_back({"production + coalesced Q rows through LDS", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.coalesced_q = true}>>});
     v.push_back({"production + packed fp32 softmax math", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.pk = true}>>});
     v.push_back({"production + last step without QK", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.skip_last_qk = true}>>});
     v.push_back({"fp32 O, direct epilogue", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.lds_epilogue32 = false}>>, 4});
