@@ -328,6 +328,20 @@ struct WaveCompute {
         return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
 
+    // ONE asm statement per group, so hipcc emits one s_waitcnt (the smallest count) for all of its operands
+    template <int F, int K>
+    __device__ __forceinline__ void pin_k() {
+        static_assert(C::WG == 2 || C::WG == 4, "wait groups of 2 or 4 fragments");
+        if constexpr (C::WG == 2) asm volatile("" : "+v"(kf[F % NPRE]), "+v"(kf[(F + 1) % NPRE]));
+        else asm volatile("" : "+v"(kf[F % NPRE]), "+v"(kf[(F + 1) % NPRE]), "+v"(kf[(F + 2) % NPRE]), "+v"(kf[(F + 3) % NPRE]));
+    }
+    template <int V, int K>
+    __device__ __forceinline__ void pin_v() {
+        constexpr int W = VPRE + 1;
+        if constexpr (C::WG == 2) asm volatile("" : "+v"(vf[V % W]), "+v"(vf[(V + 1) % W]));
+        else asm volatile("" : "+v"(vf[V % W]), "+v"(vf[(V + 1) % W]), "+v"(vf[(V + 2) % W]), "+v"(vf[(V + 3) % W]));
+    }
+
     // ---- the slots -----------------------------------------------------------------------------
     // phase A slot I: fragment f = I/(MPF*R), then (sub, row group) = ((I % (MPF*R)) / R, I % R)
     // LAST: the wave's final tile -- there is no S(t+1) to produce, so the QK^T MFMAs and their K reads are left out
@@ -338,6 +352,9 @@ struct WaveCompute {
             constexpr int f = I / (MPF * R), rem = I % (MPF * R), sub = rem / R, rg = rem % R;
             if constexpr (C::VALU_FIRST) exp_slot<I>(cur, c);   // softmax slice covers the fragment's LDS latency
             if constexpr (!LAST) {
+                // one s_waitcnt per WG fragments instead of one per MFMA: "consume" the whole group here (the SIMD
+                // issues ~1 instruction per 5 cycles over all its waves, whatever the type: every s_waitcnt costs)
+                if constexpr (C::WG > 1 && !C::MXQK && rem == 0 && f % C::WG == 0) pin_k<f, 0>();
                 qk_mfma<f, sub, rg>(kf[(f + NPRE - 1) % NPRE], kf[f % NPRE], nxt);
                 if constexpr (C::MXQK) {
                     // both fragments of a pair stay live until the pair's MFMA: refill the two window entries after it
@@ -361,7 +378,7 @@ struct WaveCompute {
     }
     // phase B slot J: V^T fragment v = J/R (16-key step v/DB, d block v%DB), row group J%R
     template <bool TRACK, int J>
-    __device__ __forceinline__ void slots_b(const Stage& st, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
+    __device__ __forceinline__ void slots_b(Stage& st, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
                                             const Scores<R>& cur, const Scores<R>& nxt) {
         if constexpr (J < SB) {
             constexpr int v = J / R, rg = J % R, s4 = v / DB, db = v % DB;
@@ -374,6 +391,8 @@ struct WaveCompute {
                 asm volatile("" :: "v"(pa));
                 o[rg][db] = mfma_32x32x16(vf[v % (VPRE + 1)], __builtin_bit_cast(bf16x8, dbg_frag), o[rg][db]);
             } else {
+                if constexpr (C::WG > 1 && rg == 0 && v % C::WG == 0) pin_v<v, 0>();
+                if constexpr (C::WG > 1 && J == SB / 2) st.pin_all();   // one vmcnt wait for the staged tile, not one per ds_write
                 o[rg][db] = mfma_32x32x16(vf[v % (VPRE + 1)], p_frag(rg, s4), o[rg][db]);
             }
             if constexpr (rg == R - 1 && v + VPRE < NB) {

@@ -40,6 +40,7 @@ struct Opt {
     bool valu_first = true;      // phase-A slots issue their softmax slice before the MFMA
     bool persist = true;         // one workgroup per CU walks a static list of units (see work_unit)
     bool lds_epilogue32 = true;  // fp32 outputs leave through LDS as whole 256-byte row pieces
+    int wg = 1;                  // K / V^T fragments consumed per s_waitcnt (1: hipcc's one wait per MFMA)
     bool coalesced_q = false;    // Q rows fetched whole and turned into fragments through LDS (see q_rows_to_fragments)
     int mxqk = -1;               // fp8 inputs: QK^T on the block-scaled 32x32x64 MFMA with unit scales (-1: on iff fp8)
     // rejected by measurement, kept as arms of the tuner
@@ -62,7 +63,7 @@ struct KernelCfg {
     static constexpr bool SKIP_LAST_QK = O.skip_last_qk;
     static constexpr bool COALESCED_Q = O.coalesced_q && O.r == 1;
     static constexpr bool MXQK = O.mxqk < 0 ? ESZ_ == 1 : O.mxqk != 0;
-    static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr;
+    static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
     static constexpr int NWAVES = 8 / O.r;           // waves per workgroup (256 query rows)
     static constexpr int DBG = O.dbg;

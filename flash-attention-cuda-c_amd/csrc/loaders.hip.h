@@ -152,6 +152,11 @@ struct BufStage {
             lds_write_b128(slot_base + G::K_TILE, vlds + n * (G::DB * 512) + W * 16, fp8x8_to_bf16x8(src[2 * W], src[2 * W + 1]));
         }
     }
+    __device__ __forceinline__ void pin_all() {   // wait for every staged load here: one asm statement = one s_waitcnt
+        static_assert(NL == 2 || NL == 4, "pin_all spells out its operands");
+        if constexpr (NL == 2) asm volatile("" : "+v"(r[0]), "+v"(r[1]));
+        else asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+    }
     template <int N = 0> __device__ __forceinline__ void load_all(int t) { if constexpr (N < NL) { load<N>(t); load_all<N + 1>(t); } }
     template <int N = 0> __device__ __forceinline__ void write_all(lds_ptr s) const { if constexpr (N < NW) { write<N>(s); write_all<N + 1>(s); } }
 };

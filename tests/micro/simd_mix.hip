@@ -30,7 +30,7 @@ __device__ __forceinline__ unsigned long long now() {
 constexpr int SLOTS = 32;   // 32 MFMAs per "tile" per wave
 
 // NFMA/NEXP/NADD/NCVT: VALU instructions per slot (x16 fixed-point: 16 = one per slot, 8 = one every second slot)
-template <int NFMA, int NEXP, int NADD, int NCVT, int NB128, int NTR, bool CHAIN, bool RANDOM = false>
+template <int NFMA, int NEXP, int NADD, int NCVT, int NB128, int NTR, bool CHAIN, bool RANDOM = false, int OPDEP = 0>
 __global__ __launch_bounds__(512) void mix_kernel(unsigned long long* out, float seed, int REP) {
     __shared__ __attribute__((aligned(16))) char lds[65536];
     const int lane = threadIdx.x & 63;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(512) void mix_kernel(unsigned long long* out, float
     f32x16 acc[4] = {{0}, {0}, {0}, {0}};
     bf16x8 fa = {1, 2, 3, 4, 5, 6, 7, 8}, fb = {1, 1, 1, 1, 1, 1, 1, 1};
     u32x4 kf[4] = {{0}, {0}, {0}, {0}};
-    u32x2 vf[4] = {{0}, {0}, {0}, {0}};
+    u32x2 vf[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
     const int off = (threadIdx.x * 16) & 32767;
     bf16x8 qf[8];
 #pragma unroll
@@ -72,6 +72,18 @@ __global__ __launch_bounds__(512) void mix_kernel(unsigned long long* out, float
                 asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(3 * (NB128 + NTR) / 16 + 1));
                 fa = __builtin_bit_cast(bf16x8, kf[s & 3]);
             }
+            if constexpr (OPDEP > 0) {
+                // like the attention kernel: EVERY MFMA waits for its own A operand, read OPDEP slots earlier --
+                // first half of the slots from one ds_read_b128, second half from two ds_read_b64_tr_b16
+                if (s < SLOTS / 2) {
+                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(OPDEP - 1));
+                    fa = __builtin_bit_cast(bf16x8, kf[s % OPDEP]);
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(2 * (OPDEP - 1)));
+                    u32x4 t = {vf[(2 * s) % (2 * OPDEP)][0], vf[(2 * s) % (2 * OPDEP)][1], vf[(2 * s + 1) % (2 * OPDEP)][0], vf[(2 * s + 1) % (2 * OPDEP)][1]};
+                    fa = __builtin_bit_cast(bf16x8, t);
+                }
+            }
             if constexpr (RANDOM) fb = qf[s & 7];
             if constexpr (CHAIN) acc[(s >> 3) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[(s >> 3) & 3], 0, 0, 0);
             else acc[s & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[s & 3], 0, 0, 0);
@@ -79,10 +91,20 @@ __global__ __launch_bounds__(512) void mix_kernel(unsigned long long* out, float
             if constexpr (NEXP > 0) if ((s * NEXP) % 16 < NEXP) asm volatile("v_exp_f32 %0, %0" : "+v"(a[(s + 2) & 7]));
             if constexpr (NADD > 0) if ((s * NADD) % 16 < NADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[(s + 4) & 7]) : "v"(seed));
             if constexpr (NCVT > 0) if ((s * NCVT) % 16 < NCVT) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(a[(s + 6) & 7]) : "v"(seed));
+            if constexpr (OPDEP > 0) {
+                // refill the operand slot just consumed (needed again OPDEP slots from now)
+                if (s < SLOTS / 2) {
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(kf[s % OPDEP]) : "v"(off + 1024 * (s & 15)));
+                } else {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vf[(2 * s) % (2 * OPDEP)]) : "v"((off >> 1) + 512 * (s & 31)));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vf[(2 * s + 1) % (2 * OPDEP)]) : "v"((off >> 1) + 512 * (s & 31) + 256));
+                }
+            } else {
             if constexpr (NB128 > 0) if ((s * NB128) % 16 < NB128)
                 asm volatile("ds_read_b128 %0, %1" : "=v"(kf[s & 3]) : "v"(off + 1024 * (s & 15)));
             if constexpr (NTR > 0) if ((s * NTR) % 16 < NTR)
                 asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vf[s & 3]) : "v"((off >> 1) + 512 * (s & 31)));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -95,7 +117,7 @@ __global__ __launch_bounds__(512) void mix_kernel(unsigned long long* out, float
 #pragma unroll
         for (int i = 0; i < 16; ++i) sum += acc[k][i];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sum += (float)(kf[k][0] + vf[k][0]);
+    for (int k = 0; k < 4; ++k) sum += (float)(kf[k][0] + vf[k][0] + vf[k + 4][0]);
     if (sum == 12345.678f) out[1000] = 1;
     if (lane == 0 && blockIdx.x == 0) out[threadIdx.x >> 6] = t1 - t0;
 }
@@ -104,7 +126,7 @@ static int g_grid = 1, g_rep = 128;
 static bool g_quiet = false;
 static double g_last_tflops = 0, g_last_clock = 0, g_last_pipe = 0;
 
-template <int NFMA, int NEXP, int NADD, int NCVT, int NB128, int NTR, bool CHAIN, bool RANDOM = false>
+template <int NFMA, int NEXP, int NADD, int NCVT, int NB128, int NTR, bool CHAIN, bool RANDOM = false, int OPDEP = 0>
 static int run(const char* name, unsigned long long* d) {
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
@@ -113,7 +135,7 @@ static int run(const char* name, unsigned long long* d) {
         float ms = 0;
         for (int i = 0; i < 3; ++i) {
             HIP_CHECK(hipEventRecord(e0, nullptr));
-            hipLaunchKernelGGL((mix_kernel<NFMA, NEXP, NADD, NCVT, NB128, NTR, CHAIN, RANDOM>), dim3(g_grid), dim3(64 * waves), 0, nullptr, d, 1.0f, g_rep);
+            hipLaunchKernelGGL((mix_kernel<NFMA, NEXP, NADD, NCVT, NB128, NTR, CHAIN, RANDOM, OPDEP>), dim3(g_grid), dim3(64 * waves), 0, nullptr, d, 1.0f, g_rep);
             HIP_CHECK(hipEventRecord(e1, nullptr));
             HIP_CHECK(hipEventSynchronize(e1));
             HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -167,5 +189,8 @@ int main(int argc, char** argv) {
     run<0, 0, 0, 0, 16, 0, false, true>("RANDOM bf16 operands: MFMA + 1 ds_read_b128 per MFMA", d);
     run<16, 16, 16, 8, 8, 16, false, true>("RANDOM bf16 operands: softmax mix + LDS mix (A from LDS)", d);
     run<16, 16, 16, 8, 4, 8, false, true>("RANDOM bf16 operands: softmax mix + half LDS mix", d);
+    run<16, 16, 16, 8, 0, 0, false, true, 2>("RANDOM: softmax mix, every MFMA waits for an LDS operand read 2 slots earlier", d);
+    run<16, 16, 16, 8, 0, 0, false, true, 4>("RANDOM: softmax mix, every MFMA waits for an LDS operand read 4 slots earlier", d);
+    run<16, 16, 16, 8, 0, 0, true, true, 2>("RANDOM: same (2 slots), first 16 MFMAs in chains of 8", d);
     return 0;
 }
