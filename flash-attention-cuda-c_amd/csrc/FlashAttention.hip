@@ -217,6 +217,7 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
     Params p;
     fill_params(p, Q, K, V, O, lse, B, H, S, Sk, d, scale, sQ, sK, sV, sO);
     p.nQ = getNumCta(S, plan.q_block_rows);
+    if ((int64_t)B * H * p.nQ > INT32_MAX / 2) return FA_ERR_BAD_SHAPE;   // unit indices are 32-bit
     p.units = B * H * p.nQ;
     p.cpx = (p.units + 7) / 8;
     p.jpx = plan.grid / 8;
