@@ -35,7 +35,7 @@ static int fill_params(Params& p, const void* Q, const void* K, const void* V, v
     p.kB = sK ? sK->strideB : kB; p.kH = sK ? sK->strideH : kH; p.kS = sK ? sK->strideS : dS;
     p.vB = sV ? sV->strideB : kB; p.vH = sV ? sV->strideH : kH; p.vS = sV ? sV->strideS : dS;
     p.oB = sO ? sO->strideB : dB; p.oH = sO ? sO->strideH : dH; p.oS = sO ? sO->strideS : dS;
-    p.B = B; p.H = H; p.S = S; p.Sk = Sk;
+    p.B = B; p.H = H; p.S = S; p.Sk = Sk; p.d = d;
     p.scale = scale;
     p.scale_log2 = scale * 1.4426950408889634f;
     return FA_OK;
@@ -88,7 +88,9 @@ static int device_cus() {
 static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_dtype, float scale,
                      fa_launch_plan* plan) {
     (void)causal;
-    const bool mfma_bf16 = dtype == FA_DTYPE_BF16 && (d == 64 || d == 128) && scale > 0.f;
+    // bf16: d in {64,128} natively; any other multiple of 8 up to 128 runs the next larger instantiation with its
+    // rows zero-padded on the fly (d/64 or d/128 of the MFMA work is useful -- still ~1000x the VALU kernel)
+    const bool mfma_bf16 = dtype == FA_DTYPE_BF16 && d % 8 == 0 && d <= 128 && scale > 0.f;
     const bool mfma_fp8 = dtype == FA_DTYPE_FP8_E4M3 && d == 128 && scale > 0.f;
     const bool mfma_f32 = dtype == FA_DTYPE_F32 && (d == 64 || d == 128) && scale > 0.f;
     if (mfma_f32) {
@@ -105,8 +107,9 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
         plan->q_block_rows = calculateSizeBlockQ(d, dtype);
         plan->kv_block_rows = calculateSizeBlockKV(d, dtype);
         plan->threads = 512;
-        // 3-slot ring of [K image (input type) | V image (bf16)]
-        plan->lds_bytes = 3 * plan->kv_block_rows * d * ((mfma_fp8 ? 1 : 2) + 2);
+        // 3-slot ring of [K image (input type) | V image (bf16)], at the instantiated head dimension
+        const int dk = mfma_fp8 ? 128 : paddedDHead(d);
+        plan->lds_bytes = 3 * plan->kv_block_rows * dk * ((mfma_fp8 ? 1 : 2) + 2);
         if (o_dtype == FA_DTYPE_F32 && plan->lds_bytes < 65536) plan->lds_bytes = 65536;   // fp32 epilogue staging (d = 64)
         // persistent grid: one workgroup per CU (8 XCD groups x CUs/8), each walking ceil(units/grid) units;
         // with fewer units than CUs, one workgroup per unit
@@ -149,11 +152,11 @@ static hipError_t launch_mfma(const Params& p, const fa_launch_plan& plan, hipSt
     return hipGetLastError();
 }
 
-template <int D, bool CAUSAL, int ESZ>
+template <int D, bool CAUSAL, int ESZ, bool PAD = false>
 static hipError_t launch_mfma_out(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
-    if (o_dtype == FA_DTYPE_F32) return launch_mfma<ProdCfg<D, CAUSAL, float, ESZ>>(p, plan, st);
-    if (o_dtype == FA_DTYPE_BF16) return launch_mfma<ProdCfg<D, CAUSAL, __bf16, ESZ>>(p, plan, st);
-    return launch_mfma<ProdCfg<D, CAUSAL, _Float16, ESZ>>(p, plan, st);
+    if (o_dtype == FA_DTYPE_F32) return launch_mfma<ProdCfg<D, CAUSAL, float, ESZ, false, PAD>>(p, plan, st);
+    if (o_dtype == FA_DTYPE_BF16) return launch_mfma<ProdCfg<D, CAUSAL, __bf16, ESZ, false, PAD>>(p, plan, st);
+    return launch_mfma<ProdCfg<D, CAUSAL, _Float16, ESZ, false, PAD>>(p, plan, st);
 }
 
 template <class Cfg>
@@ -230,8 +233,10 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
     } else if (plan.kernel_id == 2) {
         e = causal ? launch_mfma_out<128, true, 1>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 1>(p, plan, o_dtype, st);
     } else if (plan.kernel_id == 1) {
-        if (d == 128) e = causal ? launch_mfma_out<128, true, 2>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 2>(p, plan, o_dtype, st);
-        else          e = causal ? launch_mfma_out<64, true, 2>(p, plan, o_dtype, st) : launch_mfma_out<64, false, 2>(p, plan, o_dtype, st);
+        if (d == 128)     e = causal ? launch_mfma_out<128, true, 2>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 2>(p, plan, o_dtype, st);
+        else if (d == 64) e = causal ? launch_mfma_out<64, true, 2>(p, plan, o_dtype, st) : launch_mfma_out<64, false, 2>(p, plan, o_dtype, st);
+        else if (d > 64)  e = causal ? launch_mfma_out<128, true, 2, true>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 2, true>(p, plan, o_dtype, st);
+        else              e = causal ? launch_mfma_out<64, true, 2, true>(p, plan, o_dtype, st) : launch_mfma_out<64, false, 2, true>(p, plan, o_dtype, st);
     } else if (dtype == FA_DTYPE_F32) {
         e = launch_generic<float>(p, plan, d, causal, o_dtype, st);
     } else {

@@ -60,7 +60,7 @@ struct WaveCompute {
     static constexpr int NE = 32 * R;              // score elements per lane per tile
     static constexpr int SPAN = SA + (3 * SB) / 4; // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
-    using Stage = BufStage<D, ESZ, 8 / R>;
+    using Stage = BufStage<D, ESZ, 8 / R, C::PAD>;
     static constexpr int NL = Stage::NL, NW = Stage::NW;
     static_assert(2 * NL <= SA && 2 * NW <= SB / 2 + 1, "staging does not fit the slot plan");
 
@@ -97,14 +97,22 @@ struct WaveCompute {
     // Q fragment u of row q: 16 bytes at byte 32u + 16h of the row.  bf16: d = 16u + 8h .. +7 (k-step u).
     // fp8: d = 32u + 16h .. +15 -- the contraction order is permuted the same way for K (chunk 2u+h of
     // the K image), so one 16-byte fragment feeds two MFMAs.
-    __device__ __forceinline__ void load_q(const char* Qh, int64_t qS_bytes, int row0, int S, int lane) {
+    // row_bytes < D*ESZ (C::PAD): fragments past the end of the row are zero and are never read from memory.
+    __device__ __forceinline__ void load_q(const char* Qh, int64_t qS_bytes, int row0, int S, int lane, int row_bytes = D * ESZ) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             int row = row0 + 32 * r + (lane & 31);
             row = row < S ? row : S - 1;
             const char* src = Qh + row * qS_bytes + (lane >> 5) * 16;
 #pragma unroll
-            for (int u = 0; u < FPH; ++u) qf[r][u] = *reinterpret_cast<const u32x4*>(src + u * 32);
+            for (int u = 0; u < FPH; ++u) {
+                if constexpr (C::PAD) {
+                    qf[r][u] = u32x4{0u, 0u, 0u, 0u};
+                    if (u * 32 + (lane >> 5) * 16 < row_bytes) qf[r][u] = *reinterpret_cast<const u32x4*>(src + u * 32);
+                } else {
+                    qf[r][u] = *reinterpret_cast<const u32x4*>(src + u * 32);
+                }
+            }
         }
     }
     // Coalesced form (Opt::coalesced_q).  load_q above has every lane read 16-byte pieces of its own row: one
@@ -533,7 +541,7 @@ struct WaveCompute {
     // private to this wave; the caller guarantees the K/V ring is dead.
     template <typename OutT>
     __device__ __forceinline__ void store_o_lds(lds_ptr region, char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S,
-                                                int lane) {
+                                                int lane, int orow_bytes = D * 2) {
         static_assert(sizeof(OutT) == 2, "LDS epilogue is for bf16 / f16 outputs");
         constexpr int ROWB = D * 2, CHUNKS = ROWB / 16;
         const int q = lane & 31, h = lane >> 5;
@@ -564,7 +572,8 @@ struct WaveCompute {
         for (int i = 0; i < 32 * R / ROWS_PER_INST; ++i) {
             const int row = i * ROWS_PER_INST + rr;
             const u32x4 v = *reinterpret_cast<FA_LDS const u32x4*>(region + row * ROWB + (((cc ^ row) & (CHUNKS - 1)) << 4));
-            if (row0 + row < S) *reinterpret_cast<u32x4*>(Oh + (int64_t)(row0 + row) * oS_bytes + cc * 16) = v;
+            if (row0 + row < S && (!C::PAD || cc * 16 < orow_bytes))
+                *reinterpret_cast<u32x4*>(Oh + (int64_t)(row0 + row) * oS_bytes + cc * 16) = v;
         }
     }
     // 4-byte outputs through LDS, 64 columns at a time: O^T accumulators -> this wave's private region as a
@@ -574,7 +583,7 @@ struct WaveCompute {
     // `region` = 32*R*256 bytes private to this wave; the caller guarantees the K/V ring is dead.
     template <typename OutT>
     __device__ __forceinline__ void store_o_lds32(lds_ptr region, char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S,
-                                                  int lane) {
+                                                  int lane, int orow_bytes = D * 4) {
         static_assert(sizeof(OutT) == 4, "for fp32 outputs");
         const int q = lane & 31, h = lane >> 5;
         if constexpr (C::ASM_MFMA) mfma_drain();
@@ -605,7 +614,8 @@ struct WaveCompute {
             for (int i = 0; i < 8 * R; ++i) {
                 const int row = 4 * i + rr;
                 const f32x4 v = *reinterpret_cast<FA_LDS const f32x4*>(region + row * 256 + (((cc ^ row) & 15) << 4));
-                if (row0 + row < S) *reinterpret_cast<f32x4*>(Oh + (int64_t)(row0 + row) * oS_bytes + hf * 256 + cc * 16) = v;
+                if (row0 + row < S && (!C::PAD || hf * 256 + cc * 16 < orow_bytes))
+                    *reinterpret_cast<f32x4*>(Oh + (int64_t)(row0 + row) * oS_bytes + hf * 256 + cc * 16) = v;
             }
         }
     }

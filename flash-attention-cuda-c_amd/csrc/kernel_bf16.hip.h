@@ -41,6 +41,7 @@ struct Opt {
     bool persist = true;         // one workgroup per CU walks a static list of units (see work_unit)
     bool lds_epilogue32 = true;  // fp32 outputs leave through LDS as whole 256-byte row pieces
     int wg = 1;                  // K / V^T fragments consumed per s_waitcnt (1: hipcc's one wait per MFMA)
+    bool pad = false;            // the tensors' head dimension is smaller than D (multiple of 8): rows are zero-padded on the fly
     bool coalesced_q = false;    // Q rows fetched whole and turned into fragments through LDS (see q_rows_to_fragments)
     int mxqk = -1;               // fp8 inputs: QK^T on the block-scaled 32x32x64 MFMA with unit scales (-1: on iff fp8)
     // rejected by measurement, kept as arms of the tuner
@@ -61,7 +62,8 @@ struct KernelCfg {
     static constexpr bool STAMP = O.stamp, OPTIMISTIC = O.optimistic, ASM_MFMA = O.asm_mfma, VALU_FIRST = O.valu_first;
     static constexpr bool PERSIST = O.persist, LDS_EPILOGUE32 = O.lds_epilogue32, PK = O.pk, DOT2 = O.dot2;
     static constexpr bool SKIP_LAST_QK = O.skip_last_qk;
-    static constexpr bool COALESCED_Q = O.coalesced_q && O.r == 1;
+    static constexpr bool COALESCED_Q = O.coalesced_q && O.r == 1 && !O.pad;
+    static constexpr bool PAD = O.pad;
     static constexpr bool MXQK = O.mxqk < 0 ? ESZ_ == 1 : O.mxqk != 0;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
@@ -74,8 +76,8 @@ struct KernelCfg {
 };
 
 // What the library launches: the defaults of Opt.
-template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false>
-using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, Opt{.stamp = STAMP}>;
+template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false, bool PAD = false>
+using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, Opt{.stamp = STAMP, .pad = PAD}>;
 
 // One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the
 // result has to be recomputed with max tracking (only ever true for TRACK = false).
@@ -243,10 +245,11 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
     cur.set(p, g, qb, wave);
     WaveCompute<C> w;
     typename WaveCompute<C>::Stage st;
-    st.init(cur.Kh, cur.Vh, kSb, vSb, Sk, wave, lane);
+    const int row_bytes = C::PAD ? p.d * ESZ : D * ESZ, orow_bytes = C::PAD ? p.d * (int)sizeof(OutT) : D * (int)sizeof(OutT);
+    st.init(cur.Kh, cur.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
     st.load_all(0);                                 // tile 0 and Q travel together (one HBM round trip)
     if constexpr (C::COALESCED_Q) w.load_q_rows(cur.Qh, qSb, cur.q_row0, S, lane);
-    else w.load_q(cur.Qh, qSb, cur.q_row0, S, lane);
+    else w.load_q(cur.Qh, qSb, cur.q_row0, S, lane, row_bytes);
     unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     while (true) {
@@ -280,10 +283,10 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
             more = work_unit<C>(p, ++round, g, qb);
             if (more) {
                 nxt.set(p, g, qb, wave);
-                st.init(nxt.Kh, nxt.Vh, kSb, vSb, Sk, wave, lane);
+                st.init(nxt.Kh, nxt.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
                 st.load_all(0);
                 if constexpr (C::COALESCED_Q) w.load_q_rows(nxt.Qh, qSb, nxt.q_row0, S, lane);
-                else w.load_q(nxt.Qh, qSb, nxt.q_row0, S, lane);
+                else w.load_q(nxt.Qh, qSb, nxt.q_row0, S, lane, row_bytes);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -298,11 +301,11 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
             // every pass ends behind a workgroup barrier, so no wave still reads the K/V ring: reuse it
             static_assert(256 * D * 2 <= C::LDS_BYTES, "epilogue regions must fit the ring");
             if (cur.wave_live)
-                w.template store_o_lds<OutT>(smem + wave * (WROWS * D * 2), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e);
+                w.template store_o_lds<OutT>(smem + wave * (WROWS * D * 2), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e, orow_bytes);
         } else if constexpr (C::LDS_EPILOGUE32) {
             static_assert(256 * 64 * 4 <= C::LDS_BYTES, "epilogue regions must fit the ring");
             if (cur.wave_live)
-                w.template store_o_lds32<OutT>(smem + wave * (WROWS * 256), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e);
+                w.template store_o_lds32<OutT>(smem + wave * (WROWS * 256), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e, orow_bytes);
         } else {
             if (cur.wave_live) w.template store_o<OutT>(cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e);
         }

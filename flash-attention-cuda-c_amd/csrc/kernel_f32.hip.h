@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256, 2) void fwd_f32_mfma_kernel(const Params p) {
     }
 
     // staging: a wave-instruction = 8 keys x 128 bytes; wave w owns keys 8w..8w+7; load i = 128-byte piece i
-    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (int)(Sk * kSb), 0x00020000);
-    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (int)(Sk * vSb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (int)((Sk - 1) * kSb + D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (int)((Sk - 1) * vSb + D * 4), 0x00020000);
     const int skey = 8 * wave + (lane & 7), schunk = lane >> 3;      // 16-byte chunk within the 128-byte piece
     const int koff = skey * (int)kSb + schunk * 16, voff = skey * (int)vSb + schunk * 16;
     const int ktile = (int)(KVBLK * kSb), vtile = (int)(KVBLK * vSb);

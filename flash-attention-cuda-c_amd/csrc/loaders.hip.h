@@ -35,6 +35,7 @@ struct Params {
     int64_t oB, oH, oS;
     int B, H, S;      // S = query rows per head
     int Sk;           // keys (rows of K and V) per head; == S for self-attention
+    int d;            // head dimension of the tensors (<= the kernel's compile-time D: narrower rows are zero-padded)
     int nQ;           // query blocks per head
     int units;        // B*H*nQ
     int cpx;          // ceil(units / 8): work units per XCD group
@@ -90,7 +91,9 @@ __device__ __forceinline__ int v_read_base(int lane) {
 //   K lanes: key 8g + (l&7),                    16-byte chunk (l>>3)          [+8 for the second 128-byte half]
 //   V lanes: key 8g + 2*((l>>3)&3) + ((l>>2)&1), 16-byte chunk 4*(l>>5)+(l&3) [+8 ...]
 // chosen so that each 8-lane ds_write_b128 group writes 128 contiguous LDS bytes in the respective image.
-template <int D, int ESZ, int NWAVES = 8>
+// PAD: the tensors' rows hold fewer than D elements (row_bytes < ROWB): chunks past the row end are zeroed on
+// their way into LDS (the buffer read itself lands in the next row, or past the extent where it returns 0).
+template <int D, int ESZ, int NWAVES = 8, bool PAD = false>
 struct BufStage {
     using G = TileGeom<D, ESZ>;
     static constexpr int HALVES = G::ROWB / 128;                 // 128-byte halves of a row
@@ -106,12 +109,14 @@ struct BufStage {
     int ktile, vtile;      // bytes per 64-key tile step (scalar)
     int kgrp, vgrp;        // bytes per 8-key group step in global memory (scalar)
     u32x4 r[NL];           // staged data: [0,LOADS) = K, [LOADS,NL) = V
+    bool kok[HALVES], vok[HALVES];   // PAD only: this lane's chunk of each 128-byte half lies inside the row
 
     __device__ __forceinline__ void init(const char* Kh, const char* Vh, int64_t kS_bytes, int64_t vS_bytes, int S,
-                                         int wave, int lane) {
-        // descriptor inputs are blockIdx / kernarg derived -> wave-uniform; num_records = the head's extent
-        krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (int)(S * kS_bytes), 0x00020000);
-        vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (int)(S * vS_bytes), 0x00020000);
+                                         int wave, int lane, int row_bytes = G::ROWB) {
+        // descriptor inputs are blockIdx / kernarg derived -> wave-uniform; num_records = the head's extent, to
+        // the last byte of its last row (a strided view's rows are followed by other heads' data, or by nothing)
+        krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (int)((S - 1) * kS_bytes + row_bytes), 0x00020000);
+        vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (int)((S - 1) * vS_bytes + row_bytes), 0x00020000);
         ktile = (int)(64 * kS_bytes);
         vtile = (int)(64 * vS_bytes);
         kgrp = (int)(8 * kS_bytes);
@@ -123,6 +128,17 @@ struct BufStage {
         voff = vk * (int)vS_bytes + vc * 16;
         klds = G::k_lds_off(kk, kc);
         vlds = G::v_lds_off(vk, ESZ == 1 ? 2 * vc : vc);   // fp8: 16 input bytes = bf16 chunks 2c, 2c+1
+        if constexpr (PAD) {
+#pragma unroll
+            for (int hf = 0; hf < HALVES; ++hf) {
+                kok[hf] = (kc + 8 * hf) * 16 < row_bytes;
+                vok[hf] = (vc + 8 * hf) * 16 < row_bytes;
+            }
+        }
+    }
+    __device__ __forceinline__ static u32x4 keep_if(bool ok, u32x4 v) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        return ok ? v : z;
     }
     // load #N of tile t (N < LOADS: K, else V): key group g0 + n/HALVES, 128-byte half n%HALVES.  The tile
     // offset goes into the VGPR offset (v_add with scalar operands) so the hardware range check covers it.
@@ -141,10 +157,10 @@ struct BufStage {
     __device__ __forceinline__ void write(lds_ptr slot_base) const {
         if constexpr (N < LOADS) {
             constexpr int gi = N / HALVES, hf = N % HALVES;
-            lds_write_b128(slot_base, klds + gi * 128 + hf * 8192, r[N]);
+            lds_write_b128(slot_base, klds + gi * 128 + hf * 8192, PAD ? keep_if(kok[hf], r[N]) : r[N]);
         } else if constexpr (ESZ == 2) {
             constexpr int n = N - LOADS, gi = n / HALVES, hf = n % HALVES;
-            lds_write_b128(slot_base + G::K_TILE, vlds + gi * (G::DB * 512) + hf * 1024, r[N]);
+            lds_write_b128(slot_base + G::K_TILE, vlds + gi * (G::DB * 512) + hf * 1024, PAD ? keep_if(vok[hf], r[N]) : r[N]);
         } else {
             // fp8 V (ROWB = 128, one half): 16 e4m3fn bytes -> 16 bf16 (exact), two adjacent 16-byte chunks
             constexpr int n = (N - LOADS) / 2, W = (N - LOADS) % 2;   // load n of this tensor, low / high 8 bytes

@@ -19,15 +19,20 @@
 
 #include "../include/flash_attention.h"
 
+// bf16 head dimensions the MFMA kernel is instantiated for; other multiples of 8 up to 128 run the next larger one
+// with their rows zero-padded on the fly.
+inline bool bf16MfmaDHead(int d_head) { return d_head > 0 && d_head <= 128 && d_head % 8 == 0; }
+inline int paddedDHead(int d_head) { return d_head <= 64 ? 64 : 128; }
+
 inline int calculateSizeBlockQ(int d_head, int dtype) {
-    if (dtype == FA_DTYPE_BF16 && (d_head == 64 || d_head == 128)) return 256;
+    if (dtype == FA_DTYPE_BF16 && bf16MfmaDHead(d_head)) return 256;
     if (dtype == FA_DTYPE_FP8_E4M3 && d_head == 128) return 256;
     if (dtype == FA_DTYPE_F32 && (d_head == 64 || d_head == 128)) return 128;   // exact-fp32 MFMA kernel: 4 waves x 32 rows
     return 32;
 }
 
 inline int calculateSizeBlockKV(int d_head, int dtype) {
-    if (dtype == FA_DTYPE_BF16 && (d_head == 64 || d_head == 128)) return 64;
+    if (dtype == FA_DTYPE_BF16 && bf16MfmaDHead(d_head)) return 64;
     if (dtype == FA_DTYPE_FP8_E4M3 && d_head == 128) return 64;
     return 32;
 }

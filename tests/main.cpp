@@ -225,7 +225,8 @@ int main(int argc, char** argv) {
         cases.push_back({1, 2, 512, 128, 0, 1, 3, 0});    // f16 out
         cases.push_back({1, 2, 1024, 128, 0, 1, 0, 2});   // spike: forces the rescale branch
         cases.push_back({1, 2, 1024, 128, 1, 1, 0, 2});
-        cases.push_back({1, 2, 200, 80, 1, 1, 0, 0});     // bf16 on the generic path (d = 80)
+        cases.push_back({1, 2, 200, 80, 1, 1, 0, 0});     // bf16, d = 80: zero-padded onto the d = 128 MFMA kernel
+        cases.push_back({1, 2, 100, 160, 1, 1, 0, 0});    // bf16 on the generic path (d > 128)
         // fp8 e4m3fn inputs (QK^T on the fp8 MFMA, V widened to bf16 on the way into LDS)
         cases.push_back({1, 1, 64, 128, 0, 2, 0, 0});
         cases.push_back({1, 1, 64, 128, 0, 2, 0, 1});
@@ -237,6 +238,8 @@ int main(int argc, char** argv) {
             cases.push_back({8, 16, 4096, 128, 1, 1, 0, 0});  // BASELINE cfg2 (sampled heads)
             cases.push_back({8, 16, 4096, 128, 0, 1, 0, 0});
             cases.push_back({2, 8, 4096, 128, 0, 0, 0, 0});   // fp32 (the reference's own dtype) at the headline S, d
+            cases.push_back({8, 16, 4096, 96, 1, 1, 1, 0});   // bf16 d = 96 (padded onto d = 128), causal
+            cases.push_back({8, 16, 4096, 80, 0, 1, 1, 0});   // bf16 d = 80
             cases.push_back({1, 16, 16384, 128, 0, 2, 1, 0}); // BASELINE cfg3: fp8 e4m3, S=16384, d=128 (B=1, H=16 chosen)
         }
     }

@@ -73,7 +73,9 @@ def test_strided_validation():
     (1, 1, 16, 16, False, fa.FA_DTYPE_F32, 0, 32, 32),         # tests/main.cu:107
     (1, 1, 128, 64, False, fa.FA_DTYPE_F32, 3, 128, 32),       # BASELINE cfg0's shape, exact-fp32 MFMA kernel
     (2, 4, 4096, 128, True, fa.FA_DTYPE_F32, 3, 128, 32),
-    (1, 2, 200, 80, True, fa.FA_DTYPE_BF16, 0, 32, 32),        # bf16, d not in {64,128}
+    (1, 2, 200, 80, True, fa.FA_DTYPE_BF16, 1, 256, 64),       # bf16, d = 80: MFMA kernel of d = 128, rows zero-padded
+    (1, 2, 200, 40, False, fa.FA_DTYPE_BF16, 1, 256, 64),      # bf16, d = 40: MFMA kernel of d = 64
+    (1, 2, 200, 136, True, fa.FA_DTYPE_BF16, 0, 32, 32),       # bf16, d > 128: generic kernel
     (1, 16, 16384, 128, False, fa.FA_DTYPE_FP8_E4M3, 2, 256, 64),  # BASELINE cfg3 (fp8 e4m3fn)
 ])
 def test_launch_plan(B, H, S, d, causal, dtype, kid, br, bc):
@@ -87,7 +89,8 @@ def test_launch_plan(B, H, S, d, causal, dtype, kid, br, bc):
         assert p["grid"] == 8 * (-(-units // 8)) and p["grid"] >= units
     assert p["threads"] % 64 == 0 and p["lds_bytes"] <= 160 * 1024
     if kid == 1:
-        assert p["lds_bytes"] == max(3 * 2 * 64 * d * 2, 65536)   # 3-slot ring of K+V tiles; >= the fp32 epilogue's 64 KiB
+        dk = 64 if d <= 64 else 128                                 # the instantiation other head dimensions are padded to
+        assert p["lds_bytes"] == max(3 * 2 * 64 * dk * 2, 65536)  # 3-slot ring of K+V tiles; >= the fp32 epilogue's 64 KiB
     if kid == 2:
         assert p["lds_bytes"] == 3 * 64 * d * 3          # fp8 K image + bf16 V image
 

@@ -173,14 +173,15 @@ def test_fp32_path_matches_oracle(B, H, S, d, causal):
 
 BF16_CASES = [(1, 1, 64, 128, False), (1, 2, 256, 128, False), (2, 2, 512, 128, True), (1, 3, 1000, 128, True),
               (1, 3, 333, 64, False), (1, 1, 1, 128, True), (1, 2, 63, 64, True), (1, 2, 65, 128, False),
-              (2, 1, 257, 128, True), (1, 1, 2048, 64, True), (1, 2, 200, 80, True), (1, 9, 320, 128, False)]
+              (2, 1, 257, 128, True), (1, 1, 2048, 64, True), (1, 2, 200, 80, True), (1, 9, 320, 128, False),
+              (1, 2, 150, 136, True), (1, 1, 70, 256, False)]      # d > 128: generic kernel on bf16 inputs (exact fp32 math)
 
 
 @pytest.mark.parametrize("B,H,S,d,causal", BF16_CASES)
 def test_bf16_path_matches_oracle(B, H, S, d, causal):
     Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in (4, 5, 6))
     ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=causal)
-    atol, rtol = tol_for(torch.bfloat16 if d in (64, 128) else torch.float32, torch.float32)
+    atol, rtol = tol_for(torch.bfloat16 if d <= 128 else torch.float32, torch.float32)   # d <= 128: MFMA path (bf16 P)
     check(run_gpu(Q, K, V, causal), ref, atol, rtol, rms=1e-3)
 
 
@@ -324,7 +325,8 @@ CROSS_CASES = [  # dtype, B, H, Sq, Sk, d, causal
     (torch.float32, 1, 2, 260, 90, 128, True),        # fp32 MFMA kernel
     (torch.float32, 2, 1, 33, 400, 64, False),
     (torch.float32, 1, 2, 50, 77, 40, True),          # generic kernel
-    (torch.bfloat16, 1, 2, 64, 200, 80, False),       # generic kernel, bf16 inputs
+    (torch.bfloat16, 1, 2, 64, 200, 80, False),       # d = 80 padded onto the d = 128 MFMA kernel
+    (torch.bfloat16, 1, 2, 40, 90, 160, True),        # generic kernel, bf16 inputs
 ]
 
 
@@ -428,6 +430,47 @@ def test_fuzz_shapes_layouts_dtypes(i, dtype, B, H, Sq, Sk, d, causal, strided, 
     check(O.float().cpu().numpy(), ref, atol, rtol)
     np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(f(Qm, Sq), f(Km, Sk), causal=causal), rtol=2e-6,
                                atol=2e-4 if dtype == torch.float32 else 3e-3)
+
+
+@pytest.mark.parametrize("d", [8, 16, 24, 40, 56, 72, 80, 96, 104, 120])
+@pytest.mark.parametrize("causal", [False, True])
+def test_bf16_head_dims_padded_onto_the_mfma_kernel(d, causal):
+    """bf16 with d not in {64,128} (multiples of 8): runs the d = 64 / 128 MFMA instantiation with rows zero-padded
+    on the fly.  Model-layout strides (rows of other heads right behind each row, the tensor ending right behind the
+    last head's last row), ragged S, cross lengths, bf16 and fp32 outputs, LSE."""
+    B, H, Sq, Sk = 2, 3, 333, 400 if causal else 333
+    mk = lambda S, seed: randn((B, S, H * d), seed, torch.bfloat16)
+    Qm, Km, Vm = mk(Sq, 120 + d), mk(Sk, 121 + d), mk(Sk, 122 + d)
+    view = lambda t, S: t.view(B, S, H, d).transpose(1, 2)
+    f = lambda t, S: view(t, S).float().numpy()
+    ref = oracle.attention_numpy(f(Qm, Sq), f(Km, Sk), f(Vm, Sk), causal=causal)
+    for out_dtype in (torch.float32, torch.bfloat16):
+        for strided in (True, False):
+            Qd, Kd, Vd = view(Qm.to(DEV), Sq), view(Km.to(DEV), Sk), view(Vm.to(DEV), Sk)
+            if not strided:
+                Qd, Kd, Vd = Qd.contiguous(), Kd.contiguous(), Vd.contiguous()
+            O, lse = fa.flash_attention(Qd, Kd, Vd, is_causal=causal, out_dtype=out_dtype, return_lse=True)
+            torch.cuda.synchronize()
+            atol, rtol = tol_for(torch.bfloat16, out_dtype)
+            check(O.float().cpu().numpy(), ref, atol, rtol)
+            np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(f(Qm, Sq), f(Km, Sk), causal=causal), rtol=2e-6, atol=3e-3)
+    assert fa.plan(B, H, Sq, d, causal, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["kernel_id"] == 1
+
+
+def test_padded_output_rows_are_not_overrun():
+    """d = 72 into an O buffer whose rows are exactly 72 elements, with a guard band behind every row of a wider
+    allocation: the padded kernel must not write past column d."""
+    B, H, S, d, W = 1, 2, 130, 72, 128
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16).to(DEV) for s in (140, 141, 142))
+    for out_dtype in (torch.bfloat16, torch.float32):
+        buf = torch.full((B, H, S, W), 7.0, dtype=out_dtype, device=DEV)
+        O = buf[..., :d]                                    # row stride W, d columns
+        fa.flash_attention(Q, K, V, O=O, is_causal=True)
+        torch.cuda.synchronize()
+        assert bool((buf[..., d:] == 7.0).all())
+        ref = oracle.attention(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), causal=True)
+        atol, rtol = tol_for(torch.bfloat16, out_dtype)
+        check(O.float().cpu().numpy(), ref, atol, rtol)
 
 
 def test_heads_are_independent():
