@@ -92,13 +92,14 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
     // rows zero-padded on the fly (d/64 or d/128 of the MFMA work is useful -- still ~1000x the VALU kernel)
     const bool mfma_bf16 = dtype == FA_DTYPE_BF16 && d % 8 == 0 && d <= 128 && scale > 0.f;
     const bool mfma_fp8 = dtype == FA_DTYPE_FP8_E4M3 && d == 128 && scale > 0.f;
-    const bool mfma_f32 = dtype == FA_DTYPE_F32 && (d == 64 || d == 128) && scale > 0.f;
+    // fp32: d in {64,128} natively, other multiples of 4 up to 128 zero-padded onto the next larger instantiation
+    const bool mfma_f32 = dtype == FA_DTYPE_F32 && d % 4 == 0 && d <= 128 && scale > 0.f;
     if (mfma_f32) {
         plan->kernel_id = 3;
         plan->q_block_rows = calculateSizeBlockQ(d, dtype);
         plan->kv_block_rows = calculateSizeBlockKV(d, dtype);
         plan->threads = 256;
-        plan->lds_bytes = d == 128 ? F32Cfg<128, false, float>::LDS_BYTES : F32Cfg<64, false, float>::LDS_BYTES;
+        plan->lds_bytes = d > 64 ? F32Cfg<128, false, float>::LDS_BYTES : F32Cfg<64, false, float>::LDS_BYTES;
         const int nQ = getNumCta(S, plan->q_block_rows);
         const int64_t units = (int64_t)B * H * nQ;
         plan->grid = (int)(8 * ((units + 7) / 8));
@@ -168,11 +169,11 @@ static hipError_t launch_f32(const Params& p, const fa_launch_plan& plan, hipStr
     return hipGetLastError();
 }
 
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool PAD = false>
 static hipError_t launch_f32_out(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
-    if (o_dtype == FA_DTYPE_F32) return launch_f32<F32Cfg<D, CAUSAL, float>>(p, plan, st);
-    if (o_dtype == FA_DTYPE_BF16) return launch_f32<F32Cfg<D, CAUSAL, __bf16>>(p, plan, st);
-    return launch_f32<F32Cfg<D, CAUSAL, _Float16>>(p, plan, st);
+    if (o_dtype == FA_DTYPE_F32) return launch_f32<F32Cfg<D, CAUSAL, float, PAD>>(p, plan, st);
+    if (o_dtype == FA_DTYPE_BF16) return launch_f32<F32Cfg<D, CAUSAL, __bf16, PAD>>(p, plan, st);
+    return launch_f32<F32Cfg<D, CAUSAL, _Float16, PAD>>(p, plan, st);
 }
 
 template <typename InT, typename OutT>
@@ -228,8 +229,10 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
     if (plan.kernel_id == 3) {
-        if (d == 128) e = causal ? launch_f32_out<128, true>(p, plan, o_dtype, st) : launch_f32_out<128, false>(p, plan, o_dtype, st);
-        else          e = causal ? launch_f32_out<64, true>(p, plan, o_dtype, st) : launch_f32_out<64, false>(p, plan, o_dtype, st);
+        if (d == 128)     e = causal ? launch_f32_out<128, true>(p, plan, o_dtype, st) : launch_f32_out<128, false>(p, plan, o_dtype, st);
+        else if (d == 64) e = causal ? launch_f32_out<64, true>(p, plan, o_dtype, st) : launch_f32_out<64, false>(p, plan, o_dtype, st);
+        else if (d > 64)  e = causal ? launch_f32_out<128, true, true>(p, plan, o_dtype, st) : launch_f32_out<128, false, true>(p, plan, o_dtype, st);
+        else              e = causal ? launch_f32_out<64, true, true>(p, plan, o_dtype, st) : launch_f32_out<64, false, true>(p, plan, o_dtype, st);
     } else if (plan.kernel_id == 2) {
         e = causal ? launch_mfma_out<128, true, 1>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 1>(p, plan, o_dtype, st);
     } else if (plan.kernel_id == 1) {

@@ -22,8 +22,11 @@
 
 namespace fa {
 
-template <int D_, bool CAUSAL_, typename OutT_>
+// PAD_: the tensors' head dimension p.d is smaller than D_ (a multiple of 4): rows are zero-padded on the fly,
+// exactly as in the bf16 kernel (loaders.hip.h: BufStage<..., PAD>).
+template <int D_, bool CAUSAL_, typename OutT_, bool PAD_ = false>
 struct F32Cfg {
+    static constexpr bool PAD = PAD_;
     static constexpr int D = D_;
     static constexpr bool CAUSAL = CAUSAL_;
     using OutT = OutT_;
@@ -60,6 +63,7 @@ __global__ __launch_bounds__(256, 2) void fwd_f32_mfma_kernel(const Params p) {
     char* Oh = (char*)p.O + (b * p.oB + hd * p.oH) * (int64_t)sizeof(OutT);
     const int64_t qSb = p.qS * 4, kSb = p.kS * 4, vSb = p.vS * 4, oSb = p.oS * (int64_t)sizeof(OutT);
 
+    const int row_bytes = C::PAD ? p.d * 4 : D * 4, orow_bytes = C::PAD ? p.d * (int)sizeof(OutT) : D * (int)sizeof(OutT);
     const int q_row0 = qb * QBLK + wave * 32;
     const int q_end = min(S, (qb + 1) * QBLK);
     const int k_tiles = (Sk + KVBLK - 1) / KVBLK;
@@ -74,12 +78,19 @@ __global__ __launch_bounds__(256, 2) void fwd_f32_mfma_kernel(const Params p) {
         row = row < S ? row : S - 1;
         const char* src = Qh + row * qSb + h * 16;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) qv[v] = *reinterpret_cast<const f32x4*>(src + v * 32);
+        for (int v = 0; v < NV; ++v) {
+            if constexpr (C::PAD) {
+                qv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (v * 32 + h * 16 < row_bytes) qv[v] = *reinterpret_cast<const f32x4*>(src + v * 32);   // never read past the row
+            } else {
+                qv[v] = *reinterpret_cast<const f32x4*>(src + v * 32);
+            }
+        }
     }
 
     // staging: a wave-instruction = 8 keys x 128 bytes; wave w owns keys 8w..8w+7; load i = 128-byte piece i
-    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (int)((Sk - 1) * kSb + D * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (int)((Sk - 1) * vSb + D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (int)((Sk - 1) * kSb + row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (int)((Sk - 1) * vSb + row_bytes), 0x00020000);
     const int skey = 8 * wave + (lane & 7), schunk = lane >> 3;      // 16-byte chunk within the 128-byte piece
     const int koff = skey * (int)kSb + schunk * 16, voff = skey * (int)vSb + schunk * 16;
     const int ktile = (int)(KVBLK * kSb), vtile = (int)(KVBLK * vSb);
@@ -96,10 +107,13 @@ __global__ __launch_bounds__(256, 2) void fwd_f32_mfma_kernel(const Params p) {
     auto stage_write = [&](lds_ptr slot) {
 #pragma unroll
         for (int i = 0; i < C::LOADS; ++i) {
-            lds_write_b128(slot, klds + i * 8 * (KVBLK * 16), kr[i]);                   // +8 chunks per 128-byte piece
+            const bool ok = !C::PAD || (schunk + 8 * i) * 16 < row_bytes;             // chunk inside the (narrower) row?
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            const u32x4 kk = ok ? kr[i] : z, vv = ok ? vr[i] : z;
+            lds_write_b128(slot, klds + i * 8 * (KVBLK * 16), kk);                      // +8 chunks per 128-byte piece
 #pragma unroll
             for (int j = 0; j < 4; ++j)                                                   // transpose: 4 floats -> 4 rows
-                *reinterpret_cast<FA_LDS uint32_t*>(slot + C::K_TILE + vlds + (32 * i + j) * C::VT_ROW) = vr[i][j];
+                *reinterpret_cast<FA_LDS uint32_t*>(slot + C::K_TILE + vlds + (32 * i + j) * C::VT_ROW) = vv[j];
         }
     };
 
@@ -193,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void fwd_f32_mfma_kernel(const Params p) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int d0 = 32 * db + 8 * g4 + 4 * h;
+                    if (C::PAD && d0 * (int)sizeof(OutT) >= orow_bytes) continue;       // columns past the real head dimension
                     const float a = o[db][4 * g4 + 0] * inv, bq = o[db][4 * g4 + 1] * inv;
                     const float c2 = o[db][4 * g4 + 2] * inv, e = o[db][4 * g4 + 3] * inv;
                     if constexpr (sizeof(OutT) == 4) {

@@ -77,8 +77,9 @@ enum {
  *   stream      hipStream_t (passed as void* so this header needs no HIP include); NULL = the
  *               default stream
  *
- * Supported: f32 inputs, any dHead <= 256, any seqLen (exact fp32: dHead in {64,128} on the f32-input
- *            MFMA, everything else on the generic VALU kernel);
+ * Supported: f32 inputs, any dHead <= 256 with 16-byte rows, any seqLen (exact fp32: dHead <= 128 on the
+ *            f32-input MFMA -- 64 and 128 natively, other multiples of 4 zero-padded on the fly -- larger dHead on
+ *            the generic VALU kernel);
  *            bf16 inputs, any dHead <= 128 that is a multiple of 8 on the MFMA path (64 and 128 natively, the
  *            others on the next larger instantiation with rows zero-padded on the fly; any seqLen >= 1), larger
  *            dHead <= 256 on the generic path; fp8 e4m3fn inputs, dHead = 128 (QK^T on the block-scaled MFMA).

@@ -70,7 +70,8 @@ def test_strided_validation():
 @pytest.mark.parametrize("B,H,S,d,causal,dtype,kid,br,bc", [
     (8, 16, 4096, 128, True, fa.FA_DTYPE_BF16, 1, 256, 64),    # BASELINE cfg2
     (4, 8, 2048, 64, False, fa.FA_DTYPE_BF16, 1, 256, 64),     # BASELINE cfg1
-    (1, 1, 16, 16, False, fa.FA_DTYPE_F32, 0, 32, 32),         # tests/main.cu:107
+    (1, 1, 16, 16, False, fa.FA_DTYPE_F32, 3, 128, 32),        # tests/main.cu:107: d = 16 zero-padded onto the d = 64 fp32 MFMA kernel
+    (1, 2, 50, 200, False, fa.FA_DTYPE_F32, 0, 32, 32),        # fp32, d > 128: generic kernel
     (1, 1, 128, 64, False, fa.FA_DTYPE_F32, 3, 128, 32),       # BASELINE cfg0's shape, exact-fp32 MFMA kernel
     (2, 4, 4096, 128, True, fa.FA_DTYPE_F32, 3, 128, 32),
     (1, 2, 200, 80, True, fa.FA_DTYPE_BF16, 1, 256, 64),       # bf16, d = 80: MFMA kernel of d = 128, rows zero-padded

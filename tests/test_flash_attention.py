@@ -457,19 +457,42 @@ def test_bf16_head_dims_padded_onto_the_mfma_kernel(d, causal):
     assert fa.plan(B, H, Sq, d, causal, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["kernel_id"] == 1
 
 
+@pytest.mark.parametrize("d", [4, 16, 36, 60, 68, 100, 124])
+def test_fp32_head_dims_padded_onto_the_fp32_mfma_kernel(d):
+    """fp32 with d not in {64,128} (multiples of 4, e.g. the reference's own d = 16 of tests/main.cu:107): the exact
+    fp32 MFMA kernel with zero-padded rows; same tolerance as the native head dimensions."""
+    B, H, Sq, Sk = 2, 2, 150, 201
+    mk = lambda S, seed: randn((B, S, H * d), seed, torch.float32)
+    Qm, Km, Vm = mk(Sq, 150 + d), mk(Sk, 151 + d), mk(Sk, 152 + d)
+    view = lambda t, S: t.view(B, S, H, d).transpose(1, 2)
+    f = lambda t, S: view(t, S).numpy()
+    for causal in (False, True):
+        ref = oracle.attention_numpy(f(Qm, Sq), f(Km, Sk), f(Vm, Sk), causal=causal)
+        for strided in (True, False):
+            Qd, Kd, Vd = view(Qm.to(DEV), Sq), view(Km.to(DEV), Sk), view(Vm.to(DEV), Sk)
+            if not strided:
+                Qd, Kd, Vd = Qd.contiguous(), Kd.contiguous(), Vd.contiguous()
+            O, lse = fa.flash_attention(Qd, Kd, Vd, is_causal=causal, return_lse=True)
+            torch.cuda.synchronize()
+            check(O.cpu().numpy(), ref, 2e-5, 1e-4)
+            np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(f(Qm, Sq), f(Km, Sk), causal=causal), rtol=2e-6, atol=2e-4)
+    assert fa.plan(B, H, Sq, d, False, fa.FA_DTYPE_F32, fa.FA_DTYPE_F32)["kernel_id"] == 3
+
+
 def test_padded_output_rows_are_not_overrun():
     """d = 72 into an O buffer whose rows are exactly 72 elements, with a guard band behind every row of a wider
     allocation: the padded kernel must not write past column d."""
     B, H, S, d, W = 1, 2, 130, 72, 128
-    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16).to(DEV) for s in (140, 141, 142))
-    for out_dtype in (torch.bfloat16, torch.float32):
+    for in_dtype, out_dtype in ((torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float32, torch.float32),
+                                (torch.float32, torch.bfloat16)):
+        Q, K, V = (randn((B, H, S, d), s, in_dtype).to(DEV) for s in (140, 141, 142))
         buf = torch.full((B, H, S, W), 7.0, dtype=out_dtype, device=DEV)
         O = buf[..., :d]                                    # row stride W, d columns
         fa.flash_attention(Q, K, V, O=O, is_causal=True)
         torch.cuda.synchronize()
         assert bool((buf[..., d:] == 7.0).all())
         ref = oracle.attention(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), causal=True)
-        atol, rtol = tol_for(torch.bfloat16, out_dtype)
+        atol, rtol = tol_for(in_dtype, out_dtype)
         check(O.float().cpu().numpy(), ref, atol, rtol)
 
 
