@@ -66,7 +66,7 @@ static int validate(const void* Q, const void* K, const void* V, void* O, int B,
     if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP8_E4M3) return FA_ERR_UNSUPPORTED_DTYPE;
     if (o_dtype != FA_DTYPE_F32 && o_dtype != FA_DTYPE_BF16 && o_dtype != FA_DTYPE_F16) return FA_ERR_UNSUPPORTED_DTYPE;
     if (d > 256) return FA_ERR_UNSUPPORTED_DHEAD;
-    if (dtype == FA_DTYPE_FP8_E4M3 && (d != 128 || !(scale > 0.f))) return FA_ERR_UNSUPPORTED_DHEAD;   // fp8: MFMA path only
+    if (dtype == FA_DTYPE_FP8_E4M3 && (d > 128 || !(scale > 0.f))) return FA_ERR_UNSUPPORTED_DHEAD;   // fp8: MFMA path only
     if ((d * elem_size(dtype)) % 16 != 0 || (d * elem_size(o_dtype)) % 16 != 0) return FA_ERR_UNSUPPORTED_DHEAD;
     return FA_OK;
 }
@@ -91,7 +91,7 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
     // bf16: d in {64,128} natively; any other multiple of 8 up to 128 runs the next larger instantiation with its
     // rows zero-padded on the fly (d/64 or d/128 of the MFMA work is useful -- still ~1000x the VALU kernel)
     const bool mfma_bf16 = dtype == FA_DTYPE_BF16 && d % 8 == 0 && d <= 128 && scale > 0.f;
-    const bool mfma_fp8 = dtype == FA_DTYPE_FP8_E4M3 && d == 128 && scale > 0.f;
+    const bool mfma_fp8 = dtype == FA_DTYPE_FP8_E4M3 && d % 16 == 0 && d <= 128 && scale > 0.f;   // d < 128: zero-padded
     // fp32: d in {64,128} natively, other multiples of 4 up to 128 zero-padded onto the next larger instantiation
     const bool mfma_f32 = dtype == FA_DTYPE_F32 && d % 4 == 0 && d <= 128 && scale > 0.f;
     if (mfma_f32) {
@@ -234,7 +234,8 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
         else if (d > 64)  e = causal ? launch_f32_out<128, true, true>(p, plan, o_dtype, st) : launch_f32_out<128, false, true>(p, plan, o_dtype, st);
         else              e = causal ? launch_f32_out<64, true, true>(p, plan, o_dtype, st) : launch_f32_out<64, false, true>(p, plan, o_dtype, st);
     } else if (plan.kernel_id == 2) {
-        e = causal ? launch_mfma_out<128, true, 1>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 1>(p, plan, o_dtype, st);
+        if (d == 128) e = causal ? launch_mfma_out<128, true, 1>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 1>(p, plan, o_dtype, st);
+        else          e = causal ? launch_mfma_out<128, true, 1, true>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 1, true>(p, plan, o_dtype, st);
     } else if (plan.kernel_id == 1) {
         if (d == 128)     e = causal ? launch_mfma_out<128, true, 2>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 2>(p, plan, o_dtype, st);
         else if (d == 64) e = causal ? launch_mfma_out<64, true, 2>(p, plan, o_dtype, st) : launch_mfma_out<64, false, 2>(p, plan, o_dtype, st);
@@ -356,7 +357,7 @@ int flash_attention_plan(int batchSize, int numHeads, int seqLen, int dHead, boo
     if (!plan) return FA_ERR_NULL_POINTER;
     if (batchSize <= 0 || numHeads <= 0 || seqLen <= 0 || dHead <= 0) return FA_ERR_BAD_SHAPE;
     if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP8_E4M3) return FA_ERR_UNSUPPORTED_DTYPE;
-    if (dtype == FA_DTYPE_FP8_E4M3 && dHead != 128) return FA_ERR_UNSUPPORTED_DHEAD;
+    if (dtype == FA_DTYPE_FP8_E4M3 && dHead > 128) return FA_ERR_UNSUPPORTED_DHEAD;
     if (dHead > 256 || (dHead * fa::elem_size(dtype)) % 16 != 0) return FA_ERR_UNSUPPORTED_DHEAD;
     return fa::make_plan(batchSize, numHeads, seqLen, dHead, is_causal, dtype, o_dtype, 1.0f, plan);
 }

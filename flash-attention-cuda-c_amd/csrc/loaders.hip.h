@@ -164,7 +164,7 @@ struct BufStage {
         } else {
             // fp8 V (ROWB = 128, one half): 16 e4m3fn bytes -> 16 bf16 (exact), two adjacent 16-byte chunks
             constexpr int n = (N - LOADS) / 2, W = (N - LOADS) % 2;   // load n of this tensor, low / high 8 bytes
-            const u32x4 src = r[LOADS + n];
+            const u32x4 src = PAD ? keep_if(vok[0], r[LOADS + n]) : r[LOADS + n];   // e4m3fn 0x00 = +0 -> bf16 +0
             lds_write_b128(slot_base + G::K_TILE, vlds + n * (G::DB * 512) + W * 16, fp8x8_to_bf16x8(src[2 * W], src[2 * W + 1]));
         }
     }

@@ -26,14 +26,14 @@ inline int paddedDHead(int d_head) { return d_head <= 64 ? 64 : 128; }
 
 inline int calculateSizeBlockQ(int d_head, int dtype) {
     if (dtype == FA_DTYPE_BF16 && bf16MfmaDHead(d_head)) return 256;
-    if (dtype == FA_DTYPE_FP8_E4M3 && d_head == 128) return 256;
+    if (dtype == FA_DTYPE_FP8_E4M3 && d_head <= 128) return 256;
     if (dtype == FA_DTYPE_F32 && d_head > 0 && d_head <= 128 && d_head % 4 == 0) return 128;   // exact-fp32 MFMA kernel: 4 waves x 32 rows
     return 32;
 }
 
 inline int calculateSizeBlockKV(int d_head, int dtype) {
     if (dtype == FA_DTYPE_BF16 && bf16MfmaDHead(d_head)) return 64;
-    if (dtype == FA_DTYPE_FP8_E4M3 && d_head == 128) return 64;
+    if (dtype == FA_DTYPE_FP8_E4M3 && d_head <= 128) return 64;
     return 32;
 }
 

@@ -82,7 +82,8 @@ enum {
  *            the generic VALU kernel);
  *            bf16 inputs, any dHead <= 128 that is a multiple of 8 on the MFMA path (64 and 128 natively, the
  *            others on the next larger instantiation with rows zero-padded on the fly; any seqLen >= 1), larger
- *            dHead <= 256 on the generic path; fp8 e4m3fn inputs, dHead = 128 (QK^T on the block-scaled MFMA).
+ *            dHead <= 256 on the generic path; fp8 e4m3fn inputs, dHead <= 128 in multiples of 16 (QK^T on the
+ *            block-scaled MFMA; dHead < 128 zero-padded on the fly).
  *            One head's K/V extent (seqLen x row stride) must stay below 2^31 bytes on the MFMA paths.
  */
 int flash_attention(const void* Q, const void* K, const void* V, void* O,

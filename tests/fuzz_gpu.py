@@ -56,7 +56,7 @@ def main():
     for i in range(args.cases):
         dtype = [torch.bfloat16, torch.bfloat16, torch.float32, FP8][int(rng.integers(0, 4 if FP8 is not None else 3))]
         if dtype == FP8:
-            d = 128
+            d = int(rng.choice([128, 128, 64, 96, 32]))
         elif dtype == torch.float32:
             d = int(rng.choice([64, 128, 128, 16, 32, 80, 200, 256]))
         else:

@@ -44,7 +44,8 @@ def test_argument_validation_happens_before_any_launch():
     assert call(K=p + 4) == -2                                       # FA_ERR_MISALIGNED
     assert call(S=0) == -3 and call(B=-1) == -3                      # FA_ERR_BAD_SHAPE
     assert call(d=512) == -4 and call(d=3) == -4                     # FA_ERR_UNSUPPORTED_DHEAD
-    assert call(dtype=2, d=64) == -4 and call(dtype=2, d=16) == -4   # fp8 e4m3fn: d = 128 only
+    assert call(dtype=2, d=144) == -4 and call(dtype=2, d=24) == -4  # fp8 e4m3fn: d <= 128, 16-byte rows
+    assert call(dtype=2, d=64, scale=-1.0) == -4                     # fp8: MFMA path only (scale > 0)
     assert call(dtype=9) == -5 and call(o=2) == -5                   # FA_ERR_UNSUPPORTED_DTYPE
     assert call(scale=float("nan")) == -6 and call(scale=float("inf")) == -6
     for code in range(-7, 1):
@@ -78,6 +79,7 @@ def test_strided_validation():
     (1, 2, 200, 40, False, fa.FA_DTYPE_BF16, 1, 256, 64),      # bf16, d = 40: MFMA kernel of d = 64
     (1, 2, 200, 136, True, fa.FA_DTYPE_BF16, 0, 32, 32),       # bf16, d > 128: generic kernel
     (1, 16, 16384, 128, False, fa.FA_DTYPE_FP8_E4M3, 2, 256, 64),  # BASELINE cfg3 (fp8 e4m3fn)
+    (1, 4, 500, 64, True, fa.FA_DTYPE_FP8_E4M3, 2, 256, 64),       # fp8 d = 64: zero-padded onto the d = 128 instantiation
 ])
 def test_launch_plan(B, H, S, d, causal, dtype, kid, br, bc):
     p = fa.plan(B, H, S, d, causal, dtype, fa.FA_DTYPE_F32)
@@ -93,7 +95,7 @@ def test_launch_plan(B, H, S, d, causal, dtype, kid, br, bc):
         dk = 64 if d <= 64 else 128                                 # the instantiation other head dimensions are padded to
         assert p["lds_bytes"] == max(3 * 2 * 64 * dk * 2, 65536)  # 3-slot ring of K+V tiles; >= the fp32 epilogue's 64 KiB
     if kid == 2:
-        assert p["lds_bytes"] == 3 * 64 * d * 3          # fp8 K image + bf16 V image
+        assert p["lds_bytes"] == 3 * 64 * 128 * 3        # fp8 K image + bf16 V image, at the instantiated d = 128
 
 
 def test_no_cpu_fallback_in_binding():

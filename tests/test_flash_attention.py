@@ -457,6 +457,26 @@ def test_bf16_head_dims_padded_onto_the_mfma_kernel(d, causal):
     assert fa.plan(B, H, Sq, d, causal, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["kernel_id"] == 1
 
 
+@pytest.mark.skipif(FP8 is None, reason="torch build without float8_e4m3fn")
+@pytest.mark.parametrize("d", [16, 48, 64, 96, 112])
+def test_fp8_head_dims_padded_onto_the_mfma_kernel(d):
+    """fp8 e4m3fn with d < 128 (multiples of 16): the d = 128 instantiation (MX QK^T) with zero-padded rows."""
+    B, H, Sq, Sk = 2, 3, 300, 513
+    mk = lambda S, seed: randn((B, S, H * d), seed, torch.float32).to(FP8)
+    Qm, Km, Vm = mk(Sq, 160 + d), mk(Sk, 161 + d), mk(Sk, 162 + d)
+    view = lambda t, S: t.view(B, S, H, d).transpose(1, 2)
+    f = lambda t, S: view(t, S).float().numpy()
+    for causal in (False, True):
+        ref = oracle.attention_numpy(f(Qm, Sq), f(Km, Sk), f(Vm, Sk), causal=causal)
+        for strided in (True, False):
+            Qd, Kd, Vd = view(Qm.to(DEV), Sq), view(Km.to(DEV), Sk), view(Vm.to(DEV), Sk)
+            if not strided:
+                Qd, Kd, Vd = Qd.contiguous(), Kd.contiguous(), Vd.contiguous()
+            O = fa.flash_attention(Qd, Kd, Vd, is_causal=causal, out_dtype=torch.float32)
+            torch.cuda.synchronize()
+            check(O.cpu().numpy(), ref, 4e-3, 4e-3, rms=1e-3)
+
+
 @pytest.mark.parametrize("d", [4, 16, 36, 60, 68, 100, 124])
 def test_fp32_head_dims_padded_onto_the_fp32_mfma_kernel(d):
     """fp32 with d not in {64,128} (multiples of 4, e.g. the reference's own d = 16 of tests/main.cu:107): the exact
