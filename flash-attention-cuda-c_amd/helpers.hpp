@@ -11,10 +11,13 @@
 //      2 waves/SIMD is 256: O^T accumulators 16*d/32, Q fragments 4*d/16, scores 32, P 16,
 //      staging 8*d/64 -- about 200 at d = 128.
 //   Bc (keys / tile): 64.  Two 32-key score tiles per wave; K + V tile = 32 KiB at d = 128,
-//      double-buffered = 64 KiB of the CU's 160 KiB LDS.
-//   exact-fp32 MFMA kernel (fp32 inputs, d in {64,128}): Br = 128 (4 waves x 32 rows, 2 workgroups per CU),
+//      a 3-slot ring = 96 KiB of the CU's 160 KiB LDS.
+//   Grid: persistent, one workgroup per CU walking ceil(units / CUs) units (kernel_bf16.hip.h: work_unit).
+//   Head dimensions other than 64 / 128 (<= 128; multiples of 8 for bf16, 16 for fp8, 4 for fp32) run the next
+//      larger instantiation with their rows zero-padded on the fly.
+//   exact-fp32 MFMA kernel (fp32 inputs, d <= 128): Br = 128 (4 waves x 32 rows, 2 workgroups per CU),
 //      Bc = 32 (K image 16 KiB + transposed V image 18 KiB per buffer, two buffers).
-//   generic exact-fp32 kernel: Br = Bc = 32 (VALU path, any d <= 256, any seqLen).
+//   generic exact-fp32 kernel: Br = Bc = 32 (VALU path, 128 < d <= 256, any seqLen).
 #pragma once
 
 #include "../include/flash_attention.h"
