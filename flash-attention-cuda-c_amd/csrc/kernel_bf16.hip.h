@@ -42,7 +42,8 @@ struct Opt {
     bool lds_epilogue32 = true;  // fp32 outputs leave through LDS as whole 256-byte row pieces
     int wg = 1;                  // K / V^T fragments consumed per s_waitcnt (1: hipcc's one wait per MFMA)
     bool pad = false;            // the tensors' head dimension is smaller than D (multiple of 8): rows are zero-padded on the fly
-    bool coalesced_q = false;    // Q rows fetched whole and turned into fragments through LDS (see q_rows_to_fragments)
+    int coalesced_q = -1;        // Q rows fetched whole and turned into fragments through LDS (q_rows_to_fragments);
+                                 // -1: on at d = 128 (+0.8 %), off at d = 64 (the 46 us cfg1 loses 1.8 % to the extra LDS trip)
     int mxqk = -1;               // fp8 inputs: QK^T on the block-scaled 32x32x64 MFMA with unit scales (-1: on iff fp8)
     // rejected by measurement, kept as arms of the tuner
     bool pk = false;             // packed-fp32 softmax arithmetic (v_pk_fma_f32 / v_pk_add_f32): -10 %
@@ -62,7 +63,7 @@ struct KernelCfg {
     static constexpr bool STAMP = O.stamp, OPTIMISTIC = O.optimistic, ASM_MFMA = O.asm_mfma, VALU_FIRST = O.valu_first;
     static constexpr bool PERSIST = O.persist, LDS_EPILOGUE32 = O.lds_epilogue32, PK = O.pk, DOT2 = O.dot2;
     static constexpr bool SKIP_LAST_QK = O.skip_last_qk;
-    static constexpr bool COALESCED_Q = O.coalesced_q && O.r == 1 && !O.pad;
+    static constexpr bool COALESCED_Q = (O.coalesced_q < 0 ? D_ == 128 : O.coalesced_q != 0) && O.r == 1 && !O.pad;
     static constexpr bool PAD = O.pad;
     static constexpr bool MXQK = O.mxqk < 0 ? ESZ_ == 1 : O.mxqk != 0;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;

@@ -30,7 +30,7 @@ __device__ __forceinline__ unsigned long long now() {
 constexpr int SLOTS = 32;   // 32 MFMAs per "tile" per wave
 
 // NFMA/NEXP/NADD/NCVT: VALU instructions per slot (x16 fixed-point: 16 = one per slot, 8 = one every second slot)
-template <int NFMA, int NEXP, int NADD, int NCVT, int NB128, int NTR, bool CHAIN, bool RANDOM = false, int OPDEP = 0>
+template <int NFMA, int NEXP, int NADD, int NCVT, int NB128, int NTR, bool CHAIN, bool RANDOM = false, int OPDEP = 0, bool SDEP = false>
 __global__ __launch_bounds__(512) void mix_kernel(unsigned long long* out, float seed, int REP) {
     __shared__ __attribute__((aligned(16))) char lds[65536];
     const int lane = threadIdx.x & 63;
@@ -87,6 +87,11 @@ __global__ __launch_bounds__(512) void mix_kernel(unsigned long long* out, float
             if constexpr (RANDOM) fb = qf[s & 7];
             if constexpr (CHAIN) acc[(s >> 3) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[(s >> 3) & 3], 0, 0, 0);
             else acc[s & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[s & 3], 0, 0, 0);
+            if constexpr (SDEP) {
+                // like the kernel's exponent fma: its input is an accumulator element a DIFFERENT MFMA chain produced
+                // (32 MFMAs ago), its output feeds the exp below
+                asm volatile("v_fma_f32 %0, %1, %2, %2" : "=v"(a[(s + 2) & 7]) : "v"(acc[(s + 2) & 3][s & 15]), "v"(seed));
+            } else
             if constexpr (NFMA > 0) if ((s * NFMA) % 16 < NFMA) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[s & 7]) : "v"(seed));
             if constexpr (NEXP > 0) if ((s * NEXP) % 16 < NEXP) asm volatile("v_exp_f32 %0, %0" : "+v"(a[(s + 2) & 7]));
             if constexpr (NADD > 0) if ((s * NADD) % 16 < NADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[(s + 4) & 7]) : "v"(seed));
@@ -126,7 +131,7 @@ static int g_grid = 1, g_rep = 128;
 static bool g_quiet = false;
 static double g_last_tflops = 0, g_last_clock = 0, g_last_pipe = 0;
 
-template <int NFMA, int NEXP, int NADD, int NCVT, int NB128, int NTR, bool CHAIN, bool RANDOM = false, int OPDEP = 0>
+template <int NFMA, int NEXP, int NADD, int NCVT, int NB128, int NTR, bool CHAIN, bool RANDOM = false, int OPDEP = 0, bool SDEP = false>
 static int run(const char* name, unsigned long long* d) {
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
@@ -135,7 +140,7 @@ static int run(const char* name, unsigned long long* d) {
         float ms = 0;
         for (int i = 0; i < 3; ++i) {
             HIP_CHECK(hipEventRecord(e0, nullptr));
-            hipLaunchKernelGGL((mix_kernel<NFMA, NEXP, NADD, NCVT, NB128, NTR, CHAIN, RANDOM, OPDEP>), dim3(g_grid), dim3(64 * waves), 0, nullptr, d, 1.0f, g_rep);
+            hipLaunchKernelGGL((mix_kernel<NFMA, NEXP, NADD, NCVT, NB128, NTR, CHAIN, RANDOM, OPDEP, SDEP>), dim3(g_grid), dim3(64 * waves), 0, nullptr, d, 1.0f, g_rep);
             HIP_CHECK(hipEventRecord(e1, nullptr));
             HIP_CHECK(hipEventSynchronize(e1));
             HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -192,5 +197,6 @@ int main(int argc, char** argv) {
     run<16, 16, 16, 8, 0, 0, false, true, 2>("RANDOM: softmax mix, every MFMA waits for an LDS operand read 2 slots earlier", d);
     run<16, 16, 16, 8, 0, 0, false, true, 4>("RANDOM: softmax mix, every MFMA waits for an LDS operand read 4 slots earlier", d);
     run<16, 16, 16, 8, 0, 0, true, true, 2>("RANDOM: same (2 slots), first 16 MFMAs in chains of 8", d);
+    run<16, 16, 16, 8, 0, 0, false, true, 2, true>("RANDOM: same (2 slots) + the exponent fma reads MFMA accumulators", d);
     return 0;
 }
