@@ -476,19 +476,21 @@ struct WaveCompute {
         }
     }
 
-    // True iff a row sum or any O accumulator of this lane is inf / NaN (x*0 is NaN for both).
+    // True iff a row sum or any O accumulator of this lane is inf / NaN (x*0 is NaN for both).  Four independent
+    // chains: one dependent chain of 65 fmas costs ~500 cycles per unit.
     __device__ __forceinline__ bool not_finite() const {
         if constexpr (C::ASM_MFMA) mfma_drain();
-        float acc = 0.f;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            acc = fmaf(l[r], 0.f, acc);
+            acc[0] = fmaf(l[r], 0.f, acc[0]);
 #pragma unroll
             for (int i = 0; i < DB; ++i)
 #pragma unroll
-                for (int k = 0; k < 16; ++k) acc = fmaf(o[r][i][k], 0.f, acc);
+                for (int k = 0; k < 16; ++k) acc[k & 3] = fmaf(o[r][i][k], 0.f, acc[k & 3]);
         }
-        return acc != acc;
+        const float a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        return a != a;
     }
 
     // ---- epilogues -----------------------------------------------------------------------------
