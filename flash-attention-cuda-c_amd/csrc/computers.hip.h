@@ -503,7 +503,8 @@ struct WaveCompute {
     // Direct form: divide by the row sum and store O[q][d].  A lane holds d = 32db + 8g4 + 4h + (0..3).
     // Used for 4-byte outputs (the reference's float* O).  row0 = first row of the WAVE.
     template <typename OutT>
-    __device__ __forceinline__ void store_o(char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S, int lane) {
+    __device__ __forceinline__ void store_o(char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S, int lane,
+                                            int orow_bytes = D * (int)sizeof(OutT)) {
         if constexpr (C::ASM_MFMA) mfma_drain();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -519,6 +520,7 @@ struct WaveCompute {
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int d0 = 32 * db + 8 * g4 + 4 * h;
+                        if (C::PAD && d0 * (int)sizeof(OutT) >= orow_bytes) continue;   // columns past the real head dimension
                         const float a = o[r][db][4 * g4 + 0] * inv, b = o[r][db][4 * g4 + 1] * inv;
                         const float c2 = o[r][db][4 * g4 + 2] * inv, e = o[r][db][4 * g4 + 3] * inv;
                         if constexpr (sizeof(OutT) == 4) {

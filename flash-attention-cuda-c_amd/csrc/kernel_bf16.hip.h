@@ -41,6 +41,8 @@ struct Opt {
     bool persist = true;         // one workgroup per CU walks a static list of units (see work_unit)
     bool lds_epilogue32 = true;  // fp32 outputs leave through LDS as whole 256-byte row pieces
     int wg = 1;                  // K / V^T fragments consumed per s_waitcnt (1: hipcc's one wait per MFMA)
+    bool early_store = false;    // causal: a wave past its diagonal stores its (final) rows while the others still compute
+                                 // (direct scattered stores: -2..5 %, rejected)
     bool pad = false;            // the tensors' head dimension is smaller than D (multiple of 8): rows are zero-padded on the fly
     int coalesced_q = -1;        // Q rows fetched whole and turned into fragments through LDS (q_rows_to_fragments);
                                  // -1: on at d = 128 (+0.8 %), off at d = 64 (the 46 us cfg1 loses 1.8 % to the extra LDS trip)
@@ -65,6 +67,7 @@ struct KernelCfg {
     static constexpr bool SKIP_LAST_QK = O.skip_last_qk;
     static constexpr bool COALESCED_Q = (O.coalesced_q < 0 ? D_ == 128 : O.coalesced_q != 0) && O.r == 1 && !O.pad;
     static constexpr bool PAD = O.pad;
+    static constexpr bool EARLY_STORE = O.early_store && CAUSAL_ && O.r == 1 && O.optimistic;
     static constexpr bool MXQK = O.mxqk < 0 ? ESZ_ == 1 : O.mxqk != 0;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
@@ -80,12 +83,21 @@ struct KernelCfg {
 template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false, bool PAD = false>
 using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, Opt{.stamp = STAMP, .pad = PAD}>;
 
+// Where a wave's rows go, for the early store of the optimistic causal pass (see attention_pass, step kind 2).
+struct RowSink {
+    char* Oh;
+    float* lse_head;
+    int64_t oSb;
+    int orow_bytes;
+    bool stored;      // this wave's rows of the current unit have already been written
+};
+
 // One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the
 // result has to be recomputed with max tracking (only ever true for TRACK = false).
 template <class C, bool TRACK>
 __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& w, typename WaveCompute<C>::Stage& st, lds_ptr smem,
                                                int n_tiles, int my_tiles, int q_row0, int lane,
-                                               unsigned long long (&acc)[12], bool tile0_in_flight) {
+                                               unsigned long long (&acc)[12], bool tile0_in_flight, RowSink& sink) {
     using G = TileGeom<C::D, C::ESZ>;
     constexpr bool CAUSAL = C::CAUSAL;
     constexpr int KVBLK = 64, SLOT = G::SLOT, KT = G::K_TILE;
@@ -132,6 +144,18 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
         } else {
             st.load_all(t + 2);
             st.write_all(smem + so_wr);
+            if constexpr (C::EARLY_STORE && !TRACK) {
+                // This wave is past its causal diagonal: its O and l are final, and it has nothing to do but stage
+                // for the others.  Write its rows now (direct form: the LDS staging regions alias the live ring), so
+                // the epilogue after the loop is left to the waves on the diagonal.  Should the finiteness check
+                // fail afterwards, the tracked pass recomputes the block and every wave stores again.
+                if (!sink.stored && my_tiles > 0) {
+                    int lane_s = lane;   // keep the store addresses out of the tile loop's live ranges (they would spill)
+                    asm volatile("" : "+v"(lane_s));
+                    w.template store_o<typename C::OutT>(sink.Oh, sink.lse_head, sink.oSb, q_row0, p.S, lane_s, sink.orow_bytes);
+                    sink.stored = true;
+                }
+            }
         }
         if constexpr (C::STAMP) t4 = cycle_stamp();
         if constexpr (!C::DBG_NOBAR) __syncthreads();
@@ -257,6 +281,7 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
         unsigned long long t_q0 = 0;
         if constexpr (C::STAMP) t_q0 = cycle_stamp();
         w.pin_q();
+        RowSink sink{cur.Oh, cur.lse_head, oSb, orow_bytes, false};
         if constexpr (C::COALESCED_Q) {
             // staging regions sit behind ring slot 0 (tile 0 is about to be written there by other waves); every
             // wave finishes this round trip before the first barrier of the pass, after which slot 1 is written
@@ -270,10 +295,12 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
         if constexpr (C::STAMP) acc[7] += cycle_stamp() - t_q0;
 
         if constexpr (C::OPTIMISTIC) {
-            if (attention_pass<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane, acc, true))
-                attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane, acc, false);
+            if (attention_pass<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane, acc, true, sink)) {
+                sink.stored = false;   // whatever was written early came from an overflowed pass
+                attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane, acc, false, sink);
+            }
         } else {
-            attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane, acc, true);
+            attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane, acc, true, sink);
         }
 
         // Persistent grid: request the next unit's Q and tile 0 now, so their HBM round trip runs under
@@ -301,14 +328,14 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
         if constexpr (sizeof(OutT) == 2) {
             // every pass ends behind a workgroup barrier, so no wave still reads the K/V ring: reuse it
             static_assert(256 * D * 2 <= C::LDS_BYTES, "epilogue regions must fit the ring");
-            if (cur.wave_live)
+            if (cur.wave_live && !sink.stored)
                 w.template store_o_lds<OutT>(smem + wave * (WROWS * D * 2), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e, orow_bytes);
         } else if constexpr (C::LDS_EPILOGUE32) {
             static_assert(256 * 64 * 4 <= C::LDS_BYTES, "epilogue regions must fit the ring");
-            if (cur.wave_live)
+            if (cur.wave_live && !sink.stored)
                 w.template store_o_lds32<OutT>(smem + wave * (WROWS * 256), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e, orow_bytes);
         } else {
-            if (cur.wave_live) w.template store_o<OutT>(cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e);
+            if (cur.wave_live && !sink.stored) w.template store_o<OutT>(cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e, orow_bytes);
         }
         if constexpr (C::STAMP) acc[4] += cycle_stamp() - t_ep0;   // epilogue: normalise + store O (issue side)
         if (!more) break;
