@@ -165,6 +165,10 @@ struct WaveCompute {
             }
     }
 
+    __device__ __forceinline__ void k_prefetch(lds_ptr kimg, int kbase) {
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) kf[i] = k_read(kimg, kbase, i);
+    }
     __device__ __forceinline__ u32x4 k_read(lds_ptr kimg, int kbase, int f) const {
         return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + (f % FPH) * 2048 + (f / FPH) * 512));
     }
@@ -425,7 +429,8 @@ struct WaveCompute {
     template <bool TRACK, bool LAST = false>
     __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
                                               int kbase, int vbase, float c, const Scores<R>& cur, Scores<R>& nxt,
-                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
+                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane,
+                                              lds_ptr k_next2 = nullptr) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             sum_a[r] = sum_b[r] = 0.f;
@@ -436,13 +441,18 @@ struct WaveCompute {
         c2 = f32x2{c, c};
         if constexpr (!LAST) {
             if constexpr (!C::ASM_MFMA) zero(nxt);   // asm form: the first MFMA of each chain has C = 0
+            if constexpr (C::RING != 4) {            // 4-slot ring: requested before the previous barrier (k_prefetch)
 #pragma unroll
-            for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
+                for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         slots_a<0, LAST>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_mid = cycle_stamp();
         slots_b<(TRACK && !LAST), 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
+        // 4-slot ring: K(t+2) has been complete since the previous barrier, so the first fragments of the next
+        // iteration are requested here, ahead of this iteration's barrier (their latency hides behind it)
+        if constexpr (C::RING == 4 && !LAST) k_prefetch(k_next2, kbase);
         if constexpr (C::STAMP) t_end = cycle_stamp();
 #pragma unroll
         for (int r = 0; r < R; ++r) l[r] += C::PK ? sum2[r][0] + sum2[r][1] : sum_a[r] + sum_b[r];

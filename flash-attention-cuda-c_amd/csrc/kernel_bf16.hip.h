@@ -41,6 +41,8 @@ struct Opt {
     bool persist = true;         // one workgroup per CU walks a static list of units (see work_unit)
     bool lds_epilogue32 = true;  // fp32 outputs leave through LDS as whole 256-byte row pieces
     int wg = 1;                  // K / V^T fragments consumed per s_waitcnt (1: hipcc's one wait per MFMA)
+    int ring = 3;                // LDS ring slots: 3 (tile t+2 staged in iteration t) or 4 (tile t+3: K(t+2) is complete one
+                                 // iteration early, so the first K fragments of the next tile are read BEFORE the barrier)
     bool early_store = false;    // causal: a wave past its diagonal stores its (final) rows while the others still compute
                                  // (direct scattered stores: -2..5 %, rejected)
     bool pad = false;            // the tensors' head dimension is smaller than D (multiple of 8): rows are zero-padded on the fly
@@ -74,7 +76,9 @@ struct KernelCfg {
     static constexpr int NWAVES = 8 / O.r;           // waves per workgroup (256 query rows)
     static constexpr int DBG = O.dbg;
     static constexpr bool DBG_NOBAR = DBG & 1, DBG_NOLOAD = DBG & 2, DBG_PCONST = DBG & 4;
-    static constexpr int RING_BYTES = 3 * TileGeom<D_, ESZ_>::SLOT;
+    static constexpr int RING = O.ring;
+    static_assert(RING == 3 || RING == 4, "3- or 4-slot ring");
+    static constexpr int RING_BYTES = RING * TileGeom<D_, ESZ_>::SLOT;
     // the fp32 LDS epilogue stages 256 rows x 64 floats: more than the ring at d = 64
     static constexpr int LDS_BYTES = (O.lds_epilogue32 && sizeof(OutT_) == 4 && RING_BYTES < 65536) ? 65536 : RING_BYTES;
 };
@@ -117,6 +121,9 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
     st.write_all(smem);
     __syncthreads();
     st.load_all(1);          // past-the-end tiles read as zeros (buffer range check)
+    constexpr int AHEAD = C::RING - 1;                 // iteration t stages tile t + AHEAD
+    u32x4 r2[WaveCompute<C>::Stage::NL];               // 4-slot ring: tile 2 travels with tile 1
+    if constexpr (C::RING == 4) st.load_all_to(r2, 2);
     if constexpr (C::STAMP) tp1 = cycle_stamp();
     if (my_tiles > 0) {
         w.qk_all(smem, kbase, sA);
@@ -124,10 +131,13 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
         w.first_max(sA, c);   // m = row max of tile 0 (the reference of the optimistic pass)
     }
     st.write_all(smem + SLOT);
+    if constexpr (C::RING == 4) st.write_all_from(r2, smem + 2 * SLOT);
     __syncthreads();
+    if constexpr (C::RING == 4) w.k_prefetch(smem + SLOT, kbase);   // K(1) fragments of step 0 (later steps: before their barrier)
     if constexpr (C::STAMP) { tp2 = cycle_stamp(); acc[8] += tp1 - tp0; acc[9] += tp2 - tp1; }
 
-    int so_cur = 0, so_nxt = SLOT, so_wr = 2 * SLOT;   // ring slot byte offsets of tiles t, t+1, t+2
+    // ring slot byte offsets of tiles t, t+1, [t+2,] t+AHEAD
+    int so_cur = 0, so_nxt = SLOT, so_n2 = 2 * SLOT, so_wr = AHEAD * SLOT;
     // kind: 0 = full step (a next tile exists), 1 = the wave's last tile (no QK^T), 2 = staging only (the wave is
     // past its causal diagonal but still stages its share of the tiles the other waves need)
     auto step = [&](int t, int kind, Scores<C::R>& cur, Scores<C::R>& nxt) {
@@ -135,14 +145,14 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
         if constexpr (C::STAMP) t0 = cycle_stamp();
         if (kind == 0 || (kind == 1 && !C::SKIP_LAST_QK)) {
             const bool has_next = kind == 0;
-            w.template tile_step<TRACK>(st, t + 2, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
-                                        has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
+            w.template tile_step<TRACK>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
+                                        has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane, smem + so_n2);
         } else if (kind == 1) {
             if constexpr (C::SKIP_LAST_QK)
-                w.template tile_step<TRACK, true>(st, t + 2, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur,
-                                                  nxt, false, false, 0, q_row0, S, lane);
+                w.template tile_step<TRACK, true>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur,
+                                                  nxt, false, false, 0, q_row0, S, lane, smem + so_n2);
         } else {
-            st.load_all(t + 2);
+            st.load_all(t + AHEAD);
             st.write_all(smem + so_wr);
             if constexpr (C::EARLY_STORE && !TRACK) {
                 // This wave is past its causal diagonal: its O and l are final, and it has nothing to do but stage
@@ -158,7 +168,16 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
             }
         }
         if constexpr (C::STAMP) t4 = cycle_stamp();
-        if constexpr (!C::DBG_NOBAR) __syncthreads();
+        if constexpr (C::DBG_NOBAR) {
+        } else if constexpr (C::RING == 4) {
+            // __syncthreads() would drain lgkmcnt(0) and with it the K fragments just requested for the next
+            // iteration.  LDS operations of a wave complete in order, and those NPRE reads are the last ones this
+            // step issued: waiting until only they are outstanding covers every ds_write of the staged tile.
+            if (kind != 2) asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(WaveCompute<C>::NPRE) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            __syncthreads();
+        }
         if constexpr (C::STAMP) {
             t6 = cycle_stamp();
             if (kind != 2) { acc[1] += w.t_mid - t0; acc[2] += w.t_end - w.t_mid; acc[3] += t4 - w.t_end; acc[6] += 1; }
@@ -166,7 +185,8 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
         }
         const int tmp = so_cur;
         so_cur = so_nxt;
-        so_nxt = so_wr;
+        if constexpr (C::RING == 4) { so_nxt = so_n2; so_n2 = so_wr; }
+        else so_nxt = so_wr;
         so_wr = tmp;
     };
     if constexpr (C::SKIP_LAST_QK) {

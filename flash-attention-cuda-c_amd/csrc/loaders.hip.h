@@ -143,18 +143,22 @@ struct BufStage {
     // load #N of tile t (N < LOADS: K, else V): key group g0 + n/HALVES, 128-byte half n%HALVES.  The tile
     // offset goes into the VGPR offset (v_add with scalar operands) so the hardware range check covers it.
     template <int N>
-    __device__ __forceinline__ void load(int t) {
+    __device__ __forceinline__ void load(int t) { load_to<N>(r, t); }
+    template <int N>
+    __device__ __forceinline__ void load_to(u32x4 (&dst)[NL], int t) const {
         constexpr int n = N < LOADS ? N : N - LOADS;
         constexpr int gi = n / HALVES, hf = n % HALVES;
         if constexpr (N < LOADS)
-            r[N] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krsrc, koff + t * ktile + gi * kgrp + hf * 128, 0, 0));
+            dst[N] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krsrc, koff + t * ktile + gi * kgrp + hf * 128, 0, 0));
         else
-            r[N] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, voff + t * vtile + gi * vgrp + hf * 128, 0, 0));
+            dst[N] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, voff + t * vtile + gi * vgrp + hf * 128, 0, 0));
     }
     // LDS write #N: the K writes, then the V writes.  K image: +8 keys = +128 B, +8 chunks = +8 KiB.
     // V image: +8 keys = +DB*512 B, +8 bf16 chunks = +1 KiB.
     template <int N>
-    __device__ __forceinline__ void write(lds_ptr slot_base) const {
+    __device__ __forceinline__ void write(lds_ptr slot_base) const { write_from<N>(r, slot_base); }
+    template <int N>
+    __device__ __forceinline__ void write_from(const u32x4 (&r)[NL], lds_ptr slot_base) const {
         if constexpr (N < LOADS) {
             constexpr int gi = N / HALVES, hf = N % HALVES;
             lds_write_b128(slot_base, klds + gi * 128 + hf * 8192, PAD ? keep_if(kok[hf], r[N]) : r[N]);
@@ -173,6 +177,8 @@ struct BufStage {
         if constexpr (NL == 2) asm volatile("" : "+v"(r[0]), "+v"(r[1]));
         else asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
     }
+    template <int N = 0> __device__ __forceinline__ void load_all_to(u32x4 (&dst)[NL], int t) const { if constexpr (N < NL) { load_to<N>(dst, t); load_all_to<N + 1>(dst, t); } }
+    template <int N = 0> __device__ __forceinline__ void write_all_from(const u32x4 (&src)[NL], lds_ptr s) const { if constexpr (N < NW) { write_from<N>(src, s); write_all_from<N + 1>(src, s); } }
     template <int N = 0> __device__ __forceinline__ void load_all(int t) { if constexpr (N < NL) { load<N>(t); load_all<N + 1>(t); } }
     template <int N = 0> __device__ __forceinline__ void write_all(lds_ptr s) const { if constexpr (N < NW) { write<N>(s); write_all<N + 1>(s); } }
 };

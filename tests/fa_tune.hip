@@ -79,6 +79,7 @@ static std::vector<Variant> make_variants() {
     v.push_back({"waits grouped by 2 (npre4 vpre3)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .wg = 2}>>});
     v.push_back({"waits grouped by 2 (npre6 vpre3)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3, .wg = 2}>>});
     v.push_back({"waits grouped by 4 (npre8 vpre5)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 8, .vpre = 5, .wg = 4}>>});
+    v.push_back({"4-slot ring, K fragments prefetched across the barrier", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.ring = 4}>>});
     v.push_back({"early store by waves past the causal diagonal", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.early_store = true}>>});
     v.push_back({"Q as per-lane 16-byte pieces (no LDS trip)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.coalesced_q = 0}>>});
     v.push_back({"production + packed fp32 softmax math", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.pk = true}>>});
