@@ -88,7 +88,7 @@ def main():
         bad_o = ~np.isfinite(Oh) | (np.abs(Oh - ref) > error_bound(dtype, out_dtype, ref, ref_abs, smax))
         # LSE = (m + log2 l) ln 2 from fp32 scores and an fp32 sum of UNROUNDED weights: score noise + one ulp of |LSE|
         bad_l = np.abs(lh - lref) > 1e-5 + 16.0 * max(smax, 4.0) * 2.0 ** -23 + 2.0 ** -22 * np.abs(lref) + (
-            2.0 ** -14 * smax if dtype == FP8 else 0.0)
+            2.0 ** -13 * smax if dtype == FP8 else 0.0)
         key = (str(dtype).split(".")[-1], d in (64, 128))
         kinds[key] = kinds.get(key, 0) + 1
         if bad_o.any() or bad_l.any():
