@@ -200,6 +200,8 @@ def main():
                        "flop_convention": "2*B*H*S^2*d causal / 4*B*H*S^2*d non-causal",
                        "parallelism": f"batch x head shard over {n_gpus} GPU(s), no data-path collective"},
             "pct_of_bf16_mfma_peak": round(100.0 * value / (PEAK_BF16_TFLOPS * n_gpus), 2),
+            # causal FLOPs count only the unmasked half; the full-count figure alongside, labelled
+            "value_if_masked_half_counted_too": round(value * (2.0 if causal else 1.0), 2),
             "output_ok": ok_all,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
