@@ -40,21 +40,21 @@ struct Opt {
     bool valu_first = true;      // phase-A slots issue their softmax slice before the MFMA
     bool persist = true;         // one workgroup per CU walks a static list of units (see work_unit)
     bool lds_epilogue32 = true;  // fp32 outputs leave through LDS as whole 256-byte row pieces
-    int wg = 1;                  // K / V^T fragments consumed per s_waitcnt (1: hipcc's one wait per MFMA)
-    int ring = 3;                // LDS ring slots: 3 (tile t+2 staged in iteration t) or 4 (tile t+3: K(t+2) is complete one
-                                 // iteration early, so the first K fragments of the next tile are read BEFORE the barrier)
-    bool early_store = false;    // causal: a wave past its diagonal stores its (final) rows while the others still compute
-                                 // (direct scattered stores: -2..5 %, rejected)
-    bool pad = false;            // the tensors' head dimension is smaller than D (multiple of 8): rows are zero-padded on the fly
+    bool pad = false;            // the tensors' head dimension is smaller than D: rows are zero-padded on the fly
     int coalesced_q = -1;        // Q rows fetched whole and turned into fragments through LDS (q_rows_to_fragments);
                                  // -1: on at d = 128 (+0.8 %), off at d = 64 (the 46 us cfg1 loses 1.8 % to the extra LDS trip)
     int mxqk = -1;               // fp8 inputs: QK^T on the block-scaled 32x32x64 MFMA with unit scales (-1: on iff fp8)
-    // rejected by measurement, kept as arms of the tuner
+    // ---- rejected by measurement, kept as arms of the tuner (numbers: causal / non-causal headline shape) ----
+    int wg = 1;                  // K / V^T fragments consumed per s_waitcnt (1: hipcc's one wait per MFMA; 2: -2 %, 4: 0 %)
+    int ring = 3;                // LDS ring slots: 3 (tile t+2 staged in iteration t) or 4 (tile t+3: the next tile's first K
+                                 // fragments can be requested BEFORE the barrier: -3..-6 % / -1..-2 %)
+    bool early_store = false;    // causal: a wave past its diagonal stores its (final) rows while the others still compute
+                                 // (direct scattered stores: -2..-5 %)
     bool pk = false;             // packed-fp32 softmax arithmetic (v_pk_fma_f32 / v_pk_add_f32): -10 %
     bool dot2 = false;           // row sums by v_dot2_f32_bf16 over the packed weights: -3 %
-    bool skip_last_qk = false;   // a wave's last tile step without the (unused) QK^T MFMAs: -1..2 %
-    // TIMING EXPERIMENTS ONLY (wrong results by construction): bit 0 no per-tile barrier, bit 1 no global loads in the
-    // tile loop, bit 2 P.V takes a constant P (no VALU -> MFMA dependency)
+    bool skip_last_qk = false;   // a wave's last tile step without the (unused) QK^T MFMAs: -1..-2 %
+    // ---- TIMING EXPERIMENTS ONLY (wrong results by construction): bit 0 no per-tile barrier, bit 1 no global loads in
+    // the tile loop, bit 2 P.V takes a constant P (no VALU -> MFMA dependency) ----
     int dbg = 0;
 };
 
