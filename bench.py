@@ -154,11 +154,11 @@ def main():
 
     # Device priming (setup, untimed, before the W warmup steps): a GPU coming out of idle needs tens of milliseconds
     # of work before its power state and clocks settle -- with a small W the timed steps would otherwise run on the
-    # ramp (measured: 855 instead of ~980 TFLOP/s at W=5, K=20).  ~100 ms of the same launches, at most 300.
+    # ramp (measured: 855 instead of ~980 TFLOP/s at W=5, K=20).  ~100 ms of the same launches, at most 3000.
     step(); torch.cuda.synchronize()
     t_p = time.perf_counter(); step(); step(); torch.cuda.synchronize()
     t_step = max((time.perf_counter() - t_p) / 2, 1e-6)
-    for _ in range(max(0, min(300, int(0.1 / t_step)))):
+    for _ in range(max(0, min(3000, int(0.1 / t_step)))):
         step()
     torch.cuda.synchronize()
 
