@@ -9,7 +9,7 @@ KHDR     := $(wildcard $(PKG)/csrc/*.h) $(PKG)/helpers.hpp include/flash_attenti
 
 # `all` = the product, its C++ harness and driver, the oracle, the microbenchmarks bench.py uses (about 1.5 min with -j4).
 # `tune` = the kernel-variant A/B harness: ~70 kernel instantiations, 3 more minutes; not needed by tests or bench.
-all: $(LIB) oracle $(PKG)/fa_main tests/fa_test tests/micro/simd_mix tests/micro/valu_rates
+all: $(LIB) oracle $(PKG)/fa_main tests/fa_test tests/unit_kernels tests/micro/simd_mix tests/micro/valu_rates
 
 tune: tests/fa_tune
 
@@ -20,9 +20,11 @@ $(LIB): $(KSRC) $(KHDR)
 
 oracle: oracle/liboracle_attention.so
 
-# driver: the counterpart of the reference's main.cpp (device properties + run the configs)
+# driver: the counterpart of the reference's main.cpp (device properties + the BASELINE configs sharded over the GPUs;
+# RCCL reduces elapsed time and an output checksum; naive CPU attention + sampled check in the same run)
 $(PKG)/fa_main: $(PKG)/main.cpp $(LIB) include/flash_attention.h
-	$(HIPCC) -O2 -std=c++17 -o $@ $(PKG)/main.cpp -L$(PKG) -lflash_attention -Wl,-rpath,'$$ORIGIN' -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++20 -o $@ $(PKG)/main.cpp -L$(PKG) -lflash_attention -Wl,-rpath,'$$ORIGIN' \
+	    -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -lpthread
 
 # test harness: the counterpart of the reference's tests/main.cu (launch + CPU check); links the oracle
 oracle/liboracle_attention.so: oracle/cpu_attention.c oracle/cpu_attention.h
@@ -31,6 +33,10 @@ oracle/liboracle_attention.so: oracle/cpu_attention.c oracle/cpu_attention.h
 tests/fa_test: tests/main.cpp $(LIB) oracle/liboracle_attention.so
 	$(HIPCC) -O2 -std=c++17 -o $@ tests/main.cpp -L$(PKG) -lflash_attention -Loracle -loracle_attention \
 	    -Wl,-rpath,'$$ORIGIN/../$(PKG)' -Wl,-rpath,'$$ORIGIN/../oracle'
+
+# unit tests of the MFMA fragment layouts and the LDS images (run by tests/conftest.py at session start, checked by tests/test_driver.py)
+tests/unit_kernels: tests/unit_kernels.hip $(KHDR)
+	$(HIPCC) $(HIPFLAGS) -o $@ tests/unit_kernels.hip
 
 # kernel-variant A/B harness (tuning infrastructure)
 tests/fa_tune: tests/fa_tune.hip $(KHDR) oracle/liboracle_attention.so
@@ -44,6 +50,6 @@ asm: $(KSRC) $(KHDR)
 	mkdir -p build && $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/FlashAttention.s $(KSRC)
 
 clean:
-	rm -f $(LIB) $(PKG)/fa_main tests/fa_test tests/fa_tune tests/micro/simd_mix tests/micro/valu_rates oracle/liboracle_attention.so
+	rm -f $(LIB) $(PKG)/fa_main tests/fa_test tests/fa_tune tests/unit_kernels tests/micro/simd_mix tests/micro/valu_rates oracle/liboracle_attention.so
 	rm -rf build
 .PHONY: all lib tune oracle clean asm

@@ -61,6 +61,7 @@ struct WaveCompute {
     static constexpr int SPAN = SA + (3 * SB) / 4; // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
     using Stage = BufStage<D, ESZ, 8 / R, C::PAD>;
+    using ScoresT = Scores<R>;
     static constexpr int NL = Stage::NL, NW = Stage::NW;
     static_assert(2 * NL <= SA && 2 * NW <= SB / 2 + 1, "staging does not fit the slot plan");
 
@@ -192,7 +193,8 @@ struct WaveCompute {
                 mfma_qk_fp8_asm<first>(acc, a, b);
             }
         } else if constexpr (ESZ == 2) {
-            acc = mfma_32x32x16(__builtin_bit_cast(bf16x8, kfrag), __builtin_bit_cast(bf16x8, q), acc);
+            if constexpr (C::DBG_M16) acc = mfma_as_two_16x16x32(__builtin_bit_cast(bf16x8, kfrag), __builtin_bit_cast(bf16x8, q), acc, 0);
+            else acc = mfma_32x32x16(__builtin_bit_cast(bf16x8, kfrag), __builtin_bit_cast(bf16x8, q), acc);
         } else {
             const uint64_t a = (uint64_t)kfrag[2 * SUB] | ((uint64_t)kfrag[2 * SUB + 1] << 32);
             const uint64_t b = (uint64_t)q[2 * SUB] | ((uint64_t)q[2 * SUB + 1] << 32);
@@ -405,7 +407,8 @@ struct WaveCompute {
             } else {
                 if constexpr (C::WG > 1 && rg == 0 && v % C::WG == 0) pin_v<v, 0>();
                 if constexpr (C::WG > 1 && J == SB / 2) st.pin_all();   // one vmcnt wait for the staged tile, not one per ds_write
-                o[rg][db] = mfma_32x32x16(vf[v % (VPRE + 1)], p_frag(rg, s4), o[rg][db]);
+                if constexpr (C::DBG_M16) o[rg][db] = mfma_as_two_16x16x32(vf[v % (VPRE + 1)], p_frag(rg, s4), o[rg][db], 0);
+                else o[rg][db] = mfma_32x32x16(vf[v % (VPRE + 1)], p_frag(rg, s4), o[rg][db]);
             }
             if constexpr (rg == R - 1 && v + VPRE < NB) {
                 constexpr int vn = v + VPRE;

@@ -23,6 +23,9 @@
 #pragma once
 
 #include "computers.hip.h"
+#include "computers16.hip.h"
+
+#include <type_traits>
 
 namespace fa {
 
@@ -44,6 +47,8 @@ struct Opt {
     int coalesced_q = -1;        // Q rows fetched whole and turned into fragments through LDS (q_rows_to_fragments);
                                  // -1: on at d = 128 (+0.8 %), off at d = 64 (the 46 us cfg1 loses 1.8 % to the extra LDS trip)
     int mxqk = -1;               // fp8 inputs: QK^T on the block-scaled 32x32x64 MFMA with unit scales (-1: on iff fp8)
+    int m16 = -1;                // both products on v_mfma_f32_16x16x32_bf16 (computers16.hip.h) instead of 32x32x16: the chip holds
+                                 // a higher clock on that shape (power).  -1: on for bf16 inputs with r = 1
     // ---- rejected by measurement, kept as arms of the tuner (numbers: causal / non-causal headline shape) ----
     int wg = 1;                  // K / V^T fragments consumed per s_waitcnt (1: hipcc's one wait per MFMA; 2: -2 %, 4: 0 %)
     int ring = 3;                // LDS ring slots: 3 (tile t+2 staged in iteration t) or 4 (tile t+3: the next tile's first K
@@ -54,7 +59,8 @@ struct Opt {
     bool dot2 = false;           // row sums by v_dot2_f32_bf16 over the packed weights: -3 %
     bool skip_last_qk = false;   // a wave's last tile step without the (unused) QK^T MFMAs: -1..-2 %
     // ---- TIMING EXPERIMENTS ONLY (wrong results by construction): bit 0 no per-tile barrier, bit 1 no global loads in
-    // the tile loop, bit 2 P.V takes a constant P (no VALU -> MFMA dependency) ----
+    // the tile loop, bit 2 P.V takes a constant P (no VALU -> MFMA dependency), bit 3 every 32x32x16 MFMA replaced by two
+    // 16x16x32 on the same operand registers (same FLOPs, same dataflow shape: what would that MFMA shape cost / save?) ----
     int dbg = 0;
 };
 
@@ -71,11 +77,13 @@ struct KernelCfg {
     static constexpr bool PAD = O.pad;
     static constexpr bool EARLY_STORE = O.early_store && CAUSAL_ && O.r == 1 && O.optimistic;
     static constexpr bool MXQK = O.mxqk < 0 ? ESZ_ == 1 : O.mxqk != 0;
+    static constexpr bool M16 = (O.m16 < 0 ? true : O.m16 != 0) && ESZ_ == 2 && O.r == 1 && !O.asm_mfma && O.ring == 3 && !O.skip_last_qk &&
+                                !O.pk && !O.dot2 && O.wg == 1;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
     static constexpr int NWAVES = 8 / O.r;           // waves per workgroup (256 query rows)
     static constexpr int DBG = O.dbg;
-    static constexpr bool DBG_NOBAR = DBG & 1, DBG_NOLOAD = DBG & 2, DBG_PCONST = DBG & 4;
+    static constexpr bool DBG_NOBAR = DBG & 1, DBG_NOLOAD = DBG & 2, DBG_PCONST = DBG & 4, DBG_M16 = DBG & 8;
     static constexpr int RING = O.ring;
     static_assert(RING == 3 || RING == 4, "3- or 4-slot ring");
     static constexpr int RING_BYTES = RING * TileGeom<D_, ESZ_>::SLOT;
@@ -86,6 +94,10 @@ struct KernelCfg {
 // What the library launches: the defaults of Opt.
 template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false, bool PAD = false>
 using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, Opt{.stamp = STAMP, .pad = PAD}>;
+
+// The per-wave compute engine of a configuration: 16x16x32 MFMAs (computers16.hip.h) or 32x32x16 (computers.hip.h).
+template <class C>
+using WaveComputeOf = std::conditional_t<C::M16, WaveCompute16<C>, WaveCompute<C>>;
 
 // Where a wave's rows go, for the early store of the optimistic causal pass (see attention_pass, step kind 2).
 struct RowSink {
@@ -99,7 +111,7 @@ struct RowSink {
 // One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the
 // result has to be recomputed with max tracking (only ever true for TRACK = false).
 template <class C, bool TRACK>
-__device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& w, typename WaveCompute<C>::Stage& st, lds_ptr smem,
+__device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>& w, typename WaveComputeOf<C>::Stage& st, lds_ptr smem,
                                                int n_tiles, int my_tiles, int q_row0, int lane,
                                                unsigned long long (&acc)[12], bool tile0_in_flight, RowSink& sink) {
     using G = TileGeom<C::D, C::ESZ>;
@@ -109,11 +121,12 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
     unsigned long long tp0 = 0, tp1 = 0, tp2 = 0;
     if constexpr (C::STAMP) tp0 = cycle_stamp();
     w.init();
-    const int kbase = k_read_base(lane);
-    const int vbase = v_read_base(lane);
+    using WC = WaveComputeOf<C>;
+    const int kbase = C::M16 ? k16_read_base(lane) : k_read_base(lane);
+    const int vbase = C::M16 ? v16_read_base<C::D>(lane) : v_read_base(lane);
     const float c = p.scale_log2;
     auto needs_mask = [&](int t) { return (CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > S); };
-    Scores<C::R> sA, sB;
+    typename WC::ScoresT sA, sB;
 
     // Prologue: tile 0 (requested by the caller together with Q on the first pass) -> LDS, barrier; then
     // tile 1 is fetched while S(0) = K(0).Q^T and its row max are computed.
@@ -122,7 +135,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
     __syncthreads();
     st.load_all(1);          // past-the-end tiles read as zeros (buffer range check)
     constexpr int AHEAD = C::RING - 1;                 // iteration t stages tile t + AHEAD
-    u32x4 r2[WaveCompute<C>::Stage::NL];               // 4-slot ring: tile 2 travels with tile 1
+    u32x4 r2[WC::Stage::NL];                           // 4-slot ring: tile 2 travels with tile 1
     if constexpr (C::RING == 4) st.load_all_to(r2, 2);
     if constexpr (C::STAMP) tp1 = cycle_stamp();
     if (my_tiles > 0) {
@@ -140,7 +153,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
     int so_cur = 0, so_nxt = SLOT, so_n2 = 2 * SLOT, so_wr = AHEAD * SLOT;
     // kind: 0 = full step (a next tile exists), 1 = the wave's last tile (no QK^T), 2 = staging only (the wave is
     // past its causal diagonal but still stages its share of the tiles the other waves need)
-    auto step = [&](int t, int kind, Scores<C::R>& cur, Scores<C::R>& nxt) {
+    auto step = [&](int t, int kind, typename WC::ScoresT& cur, typename WC::ScoresT& nxt) {
         unsigned long long t0 = 0, t4 = 0, t6 = 0;
         if constexpr (C::STAMP) t0 = cycle_stamp();
         if (kind == 0 || (kind == 1 && !C::SKIP_LAST_QK)) {
@@ -173,7 +186,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
             // __syncthreads() would drain lgkmcnt(0) and with it the K fragments just requested for the next
             // iteration.  LDS operations of a wave complete in order, and those NPRE reads are the last ones this
             // step issued: waiting until only they are outstanding covers every ds_write of the staged tile.
-            if (kind != 2) asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(WaveCompute<C>::NPRE) : "memory");
+            if (kind != 2) asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(WC::NPRE) : "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
             __syncthreads();
@@ -288,8 +301,8 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
 
     UnitCtx<C> cur;
     cur.set(p, g, qb, wave);
-    WaveCompute<C> w;
-    typename WaveCompute<C>::Stage st;
+    WaveComputeOf<C> w;
+    typename WaveComputeOf<C>::Stage st;
     const int row_bytes = C::PAD ? p.d * ESZ : D * ESZ, orow_bytes = C::PAD ? p.d * (int)sizeof(OutT) : D * (int)sizeof(OutT);
     st.init(cur.Kh, cur.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
     st.load_all(0);                                 // tile 0 and Q travel together (one HBM round trip)
@@ -314,13 +327,18 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
         }
         if constexpr (C::STAMP) acc[7] += cycle_stamp() - t_q0;
 
+        // Lane-derived values of the pass (read bases, the 32 mask compares of tile 0, ...) are unit-invariant: hipcc
+        // hoists them out of the unit loop, runs out of SGPRs for the compare masks and spills across the tile loop.
+        // An opaque copy of the lane id keeps them inside the pass.
+        int lane_p = lane;
+        if constexpr (C::PERSIST) asm volatile("" : "+v"(lane_p));
         if constexpr (C::OPTIMISTIC) {
-            if (attention_pass<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane, acc, true, sink)) {
+            if (attention_pass<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true, sink)) {
                 sink.stored = false;   // whatever was written early came from an overflowed pass
-                attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane, acc, false, sink);
+                attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false, sink);
             }
         } else {
-            attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane, acc, true, sink);
+            attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true, sink);
         }
 
         // Persistent grid: request the next unit's Q and tile 0 now, so their HBM round trip runs under
@@ -333,8 +351,12 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
                 nxt.set(p, g, qb, wave);
                 st.init(nxt.Kh, nxt.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
                 st.load_all(0);
-                if constexpr (C::COALESCED_Q) w.load_q_rows(nxt.Qh, qSb, nxt.q_row0, S, lane);
-                else w.load_q(nxt.Qh, qSb, nxt.q_row0, S, lane, row_bytes);
+                // (opaque lane: a hoisted per-lane Q address is spilled across the tile loop, and its reload's vmcnt(0)
+                // would make the Q loads wait for the tile-0 loads just issued)
+                int lane_n = lane;
+                asm volatile("" : "+v"(lane_n));
+                if constexpr (C::COALESCED_Q) w.load_q_rows(nxt.Qh, qSb, nxt.q_row0, S, lane_n);
+                else w.load_q(nxt.Qh, qSb, nxt.q_row0, S, lane_n, row_bytes);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

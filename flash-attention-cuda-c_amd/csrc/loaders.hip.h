@@ -75,6 +75,12 @@ struct TileGeom {
     __host__ __device__ static constexpr int v_lds_off(int key, int chunk) {
         return (key >> 3) * (DB * 512) + (chunk >> 2) * 512 + (key & 7) * 64 + (chunk & 3) * 16;
     }
+    // V image of the 16x16x32 kernels: bf16 [key/8][d/16][key%8][d%16] -- one (8 keys x 16 d) subtile is 256
+    // contiguous bytes, exactly what one half-wave of a ds_read_b64_tr_b16 of the 16-wide V^T fragment touches.
+    static constexpr int DG = D / 16;
+    __host__ __device__ static constexpr int v16_lds_off(int key, int chunk) {
+        return (key >> 3) * (DG * 256) + (chunk >> 1) * 256 + (key & 7) * 32 + (chunk & 1) * 16;
+    }
 };
 
 // Per-lane LDS read bases (everything else is an immediate offset).
@@ -85,6 +91,16 @@ __device__ __forceinline__ int v_read_base(int lane) {
     const int h = lane >> 5, q = (lane & 15) >> 2, p = lane & 3, g = (lane >> 4) & 1;
     return 256 * h + 64 * q + 32 * g + 8 * p;
 }
+// 16x16x32 kernels (computers16.hip.h).  K A-fragment of 16-key group kg, 32-wide k-step ks: lane (key r = l&15, quarter
+// h4 = l>>4) reads 16-byte chunk 4*ks + h4 of key 16*kg + r:  k16_read_base + ks*4096 + kg*256.
+// V^T A-fragment of 16-wide d group dg, 32-key step kk, half jj: the 16 lanes of quarter h4 transpose-read keys
+// 32*kk + 16*jj + 4*h4 + (0..3) x d 16*dg .. +15:  v16_read_base + (4*kk + 2*jj)*DG*256 + dg*256.
+__device__ __forceinline__ int k16_read_base(int lane) { return (lane >> 4) * 1024 + (lane & 15) * 16; }
+template <int D>
+__device__ __forceinline__ int v16_read_base(int lane) {
+    const int h4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    return (h4 >> 1) * (D / 16 * 256) + (4 * (h4 & 1) + q) * 32 + 8 * p;
+}
 
 // K/V tile staging.  One wave-instruction = 8 keys x 128 bytes.  A 64-key tile is 8 key groups x
 // (ROWB/128) column halves; with NWAVES waves each wave owns GPW = 8/NWAVES consecutive key groups.
@@ -93,7 +109,10 @@ __device__ __forceinline__ int v_read_base(int lane) {
 // chosen so that each 8-lane ds_write_b128 group writes 128 contiguous LDS bytes in the respective image.
 // PAD: the tensors' rows hold fewer than D elements (row_bytes < ROWB): chunks past the row end are zeroed on
 // their way into LDS (the buffer read itself lands in the next row, or past the extent where it returns 0).
-template <int D, int ESZ, int NWAVES = 8, bool PAD = false>
+// V16: the V image of the 16x16x32 kernels (TileGeom::v16_lds_off); its lanes are
+//   V lanes: key 8g + 4*((l>>3)&1) + ((l&7)>>1), 16-byte chunk 2*(l>>4) + (l&1)  [+8 for the second 128-byte half]
+// (each 8-lane group still writes 128 contiguous LDS bytes; +8 keys and +8 chunks cost the same strides as above).
+template <int D, int ESZ, int NWAVES = 8, bool PAD = false, bool V16 = false>
 struct BufStage {
     using G = TileGeom<D, ESZ>;
     static constexpr int HALVES = G::ROWB / 128;                 // 128-byte halves of a row
@@ -123,11 +142,13 @@ struct BufStage {
         vgrp = (int)(8 * vS_bytes);
         const int g0 = wave * GPW;
         const int kk = 8 * g0 + (lane & 7), kc = lane >> 3;
-        const int vk = 8 * g0 + 2 * ((lane >> 3) & 3) + ((lane >> 2) & 1), vc = 4 * (lane >> 5) + (lane & 3);
+        const int vk = V16 ? 8 * g0 + 4 * ((lane >> 3) & 1) + ((lane & 7) >> 1) : 8 * g0 + 2 * ((lane >> 3) & 3) + ((lane >> 2) & 1);
+        const int vc = V16 ? 2 * (lane >> 4) + (lane & 1) : 4 * (lane >> 5) + (lane & 3);
         koff = kk * (int)kS_bytes + kc * 16;
         voff = vk * (int)vS_bytes + vc * 16;
         klds = G::k_lds_off(kk, kc);
-        vlds = G::v_lds_off(vk, ESZ == 1 ? 2 * vc : vc);   // fp8: 16 input bytes = bf16 chunks 2c, 2c+1
+        static_assert(!(V16 && ESZ == 1), "the 16x16x32 V image takes bf16 inputs");
+        vlds = V16 ? G::v16_lds_off(vk, vc) : G::v_lds_off(vk, ESZ == 1 ? 2 * vc : vc);   // fp8: 16 input bytes = bf16 chunks 2c, 2c+1
         if constexpr (PAD) {
 #pragma unroll
             for (int hf = 0; hf < HALVES; ++hf) {

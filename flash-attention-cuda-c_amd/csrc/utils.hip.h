@@ -35,6 +35,23 @@ typedef FA_LDS char* lds_ptr;
 __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// 16x16 output tile, K = 32 (computers16.hip.h).  Operand lane maps: lane l, r = l&15, h4 = l>>4 holds A[row r][k = 8*h4 + j],
+// B[k = 8*h4 + j][col r], j = 0..7; C/D: col = l&15, row = 4*h4 + reg (reg 0..3).  Same FLOPs per cycle as the 32x32x16
+// form, but half the accumulator traffic per FLOP: on random data the chip holds a ~10-25 % higher clock on it.
+__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// TIMING EXPERIMENT ONLY (Opt::dbg bit 3): two 16x16x32 MFMAs on the operands of one 32x32x16 -- same FLOPs, same
+// operand registers, half the accumulator registers written.  The numbers that come out mean nothing.
+__device__ __forceinline__ f32x16 mfma_as_two_16x16x32(bf16x8 a, bf16x8 b, f32x16 c, int which) {
+    f32x4 lo = {c[0], c[1], c[2], c[3]}, hi = {c[4], c[5], c[6], c[7]};
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, hi, 0, 0, 0);
+    c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3];
+    c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
+    (void)which;
+    return c;
+}
 __device__ __forceinline__ f32x16 mfma_32x32x16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
@@ -108,6 +125,25 @@ __device__ __forceinline__ float max_both_halves(float x) {
     const uint32_t u = __float_as_uint(x);
     auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// ---- reductions over the four 16-lane quarters (lanes l, l^16, l^32, l^48): a softmax row of the 16x16x32 kernels ----
+// v_permlane16_swap vdst, src swaps vdst's odd 16-lane rows with src's even rows: with both = x the pair holds
+// {x[row^1] on one side, own on the other}; v_permlane32_swap then does the same for the two 32-lane halves.
+__device__ __forceinline__ float max_all_quarters(float x) {
+    const uint32_t u = __float_as_uint(x);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const uint32_t v = __float_as_uint(y);
+    auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float sum_all_quarters(float x) {
+    const uint32_t u = __float_as_uint(x);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const uint32_t v = __float_as_uint(y);
+    auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float sum_both_halves(float x) {
     const uint32_t u = __float_as_uint(x);

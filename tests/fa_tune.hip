@@ -75,7 +75,9 @@ template <int D, bool CAUSAL>
 static std::vector<Variant> make_variants() {
     using T = __bf16;
     std::vector<Variant> v;
-    v.push_back({"production (persistent, optimistic)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
+    v.push_back({"production (16x16x32 MFMAs)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
+    v.push_back({"32x32x16 MFMAs (round-1 production)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0}>>});
+#ifdef FA_TUNE_FULL   // the round-1 arms (rejected by measurement): ~3 more minutes of compile time
     v.push_back({"waits grouped by 2 (npre4 vpre3)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .wg = 2}>>});
     v.push_back({"waits grouped by 2 (npre6 vpre3)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3, .wg = 2}>>});
     v.push_back({"waits grouped by 4 (npre8 vpre5)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 8, .vpre = 5, .wg = 4}>>});
@@ -91,12 +93,16 @@ static std::vector<Variant> make_variants() {
     v.push_back({"EXPERIMENT no global loads in loop (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 2}>>});
     v.push_back({"EXPERIMENT P.V takes constant P (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 4}>>});
     v.push_back({"EXPERIMENT no barrier + no loads + constant P (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 7}>>});
-    v.push_back({"one unit per workgroup (r01 a-j)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.persist = false}>>});
+#endif
+    v.push_back({"EXPERIMENT two 16x16x32 per 32x32x16 (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0, .dbg = 8}>>});
     v.push_back({"R=2 asm persistent (experimental)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.r = 2, .asm_mfma = true}>>});
+#ifdef FA_TUNE_FULL
+    v.push_back({"one unit per workgroup (r01 a-j)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.persist = false}>>});
     v.push_back({"tracked only (persistent)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.optimistic = false}>>});
     v.push_back({"persistent npre6 vpre3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3}>>});
     v.push_back({"MFMA-first slots (old order)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = false}>>});
     v.push_back({"one unit per workgroup STAMP", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.stamp = true, .persist = false}>>});
+#endif
     v.push_back({"production STAMP", launch_cfg<ProdCfg<D, CAUSAL, T, 2, true>>});
     return v;
 }
@@ -179,8 +185,10 @@ int main(int argc, char** argv) {
     if (fp8 && d == 128) vars = causal ? make_variants_fp8<true>() : make_variants_fp8<false>();
     else if (fp8) { fprintf(stderr, "--fp8 needs d = 128\n"); return 2; }
     else if (d == 128) vars = causal ? make_variants<128, true>() : make_variants<128, false>();
+#if defined(FA_TUNE_FULL) || defined(FA_TUNE_D64)
     else if (d == 64) vars = causal ? make_variants<64, true>() : make_variants<64, false>();
-    else { fprintf(stderr, "d must be 64 or 128\n"); return 2; }
+#endif
+    else { fprintf(stderr, "d must be 128 (or 64 in a -DFA_TUNE_D64 / -DFA_TUNE_FULL build)\n"); return 2; }
     if (!only.empty()) {
         std::vector<Variant> sel;
         for (int i : only) if (i >= 0 && i < (int)vars.size()) sel.push_back(vars[i]);
