@@ -9,12 +9,18 @@ A "step" is one pass of the hot path (one flash_attention launch) over one batch
 N(0,1) bf16 tensors already resident in HBM.  Default workload = BASELINE.json configs[2], the
 configuration the metric is quoted on: bf16, B=8, H=16, S=4096, d=128, causal.  With N > 1 every
 rank runs that same per-GPU batch on its own heads (weak scaling: the path shards over batch x head
-with no data-path collective; RCCL carries only the MAX of elapsed times, outside the timed region).
+with no data-path collective; RCCL carries only the MAX of elapsed times, outside the timed region),
+and the line also carries a `cfg4` sub-record: BASELINE configs[4] (B=64, H=32, S=8192, d=128) with its
+2048 heads split over the N ranks (strong scaling), a few steps.
 FLOPs: 4*B*H*S^2*d non-causal, 2*B*H*S^2*d causal (only unmasked work counts) -- SURVEY.md 8(d).
 
-Rank 0 prints ONE JSON line with `roofline` (HIP-event kernel time vs the 2516.6 TFLOP/s bf16 MFMA
-peak) and, at N=1, `cpu_baseline` (the oracle's naive fp32 attention timed on the host cores over a
-bounded sample of the same workload).
+Rank 0 prints ONE JSON line with
+  `roofline`      HIP-event kernel time against the bound that applies to the workload (see bound_for), the HBM traffic
+                  measured by the committed PMC run IF it was taken on the same kernel sources (provenance hash), and
+  `cpu_baseline`  (N=1) the oracle's naive fp32 attention timed on the host cores over a bounded sample of THIS run's own
+                  tensors, whose result is also the checker for `parity`: max-abs / max-rel error and the fraction of
+                  elements inside the stated tolerance |O-ref| <= 1e-3 + 1e-3|ref|.
+`--dry-run` (CPU, gloo): no kernel is launched and nothing is measured -- the line's STRUCTURE for N ranks (tests).
 """
 from __future__ import annotations
 
@@ -26,8 +32,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "profiles"))
 
 PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md)
+METRIC = "fwd attention TFLOP/s/GPU (bf16, seq=4096, d=128) + % MFMA peak"   # BASELINE.json, verbatim
 
 WORKLOADS = {
     # name: (B, H, S, d, causal, description)
@@ -43,16 +51,46 @@ def flops_of(BH, S, d, causal):
     return (2.0 if causal else 4.0) * BH * float(S) * S * d
 
 
+def bound_for(workload):
+    """(bound, peak TFLOP/s, derivation) of the dominant kernel for a workload.
+
+    The SIMD's vector-issue port serves BOTH waves of a SIMD one instruction at a time: an MFMA holds it 8 cycles, v_exp_f32 8,
+    v_fma_f32 / v_cvt_pk 4 (MI355X_MICROARCH.md 'vector-instruction ISSUE cost'; tests/micro/valu_rates).  Per wave and 64-key
+    tile the 16x16x32 engine issues D/2 + 4 MFMAs and 32 x (fma + exp) + 16 cvt_pk; the MFMA pipe is busy 16 cycles per
+    MFMA.  d = 128: 68 MFMAs -> 1088 pipe cycles against 992 vector-issue cycles: the pipe binds -> "mfma", nominal peak.
+    d = 64: 36 MFMAs -> 576 pipe cycles against 736 vector-issue cycles: vector issue binds -> "valu", and the peak is the
+    MFMA peak scaled by useful-MFMA pipe cycles / vector-issue cycles = 2516.6 * 512 / 736.
+    fp8 (cfg3): QK^T on the block-scaled MX MFMA at twice the bf16 rate, P.V at the bf16 rate: time-weighted mix."""
+    if workload == "cfg3":
+        return "mfma", 1.0 / (0.5 / (2 * PEAK_BF16_TFLOPS) + 0.5 / PEAK_BF16_TFLOPS), "0.5 of the FLOPs at the MX fp8 rate (2x), 0.5 at the bf16 rate"
+    d = WORKLOADS[workload][3]
+    n_mfma = d // 2 + 4              # QK^T: 4 key groups x d/32 k-steps x 2 query groups; P.V: d/16 x 2 x 2; 4 row-sum MFMAs
+    pipe, issue, useful = 16 * n_mfma, 8 * n_mfma + 32 * (4 + 8) + 16 * 4, 16 * (n_mfma - 4)
+    if issue > pipe:
+        return "valu", PEAK_BF16_TFLOPS * useful / issue, f"vector issue {issue} > MFMA pipe {pipe} cycles per wave-tile; peak = MFMA peak x {useful}/{issue}"
+    return "mfma", PEAK_BF16_TFLOPS, f"MFMA pipe {pipe} >= vector issue {issue} cycles per wave-tile; nominal dense bf16 peak"
+
+
 def measured_traffic(workload):
-    """HBM bytes per launch from the committed PMC run of this same command (separate FETCH_SIZE / WRITE_SIZE
-    passes, FETCH_SIZE doubled as the gfx950 guide prescribes) -- profiles/r01_hbm_traffic_<workload>.json;
-    None when no such measurement is committed for the workload."""
-    path = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_{workload}.json")
+    """HBM bytes per launch from the committed PMC run of this same command (separate FETCH_SIZE / WRITE_SIZE passes,
+    FETCH_SIZE doubled as the gfx950 guide prescribes) -- profiles/r02_hbm_traffic_<workload>.json -- but ONLY if that run
+    was taken on the kernel sources that are built now (sha256 over csrc/, profiles/provenance.py): a measurement of
+    other code is not this run's traffic.  Returns (bytes or None, provenance dict)."""
+    import provenance
+    path = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_{workload}.json")
+    now = provenance.csrc_sha256()
     try:
         with open(path) as f:
-            return int(json.load(f)["traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None, {"file": None, "csrc_sha256_now": now}
+    same = rec.get("csrc_sha256") == now
+    prov = {"file": os.path.relpath(path, ROOT), "csrc_sha256_measured": rec.get("csrc_sha256"), "csrc_sha256_now": now,
+            "matches_built_sources": same}
+    try:
+        return (int(rec["traffic_bytes_per_launch"]) if same else None), prov
+    except (KeyError, ValueError):
+        return None, prov
 
 
 def power_limited_ceiling():
@@ -60,7 +98,7 @@ def power_limited_ceiling():
     CU, 2 waves per SIMD of (a) back-to-back v_mfma_f32_32x32x16_bf16 and (b) the attention kernel's own
     per-MFMA instruction mix (softmax VALU ops + K / V^T LDS reads), both on RANDOM bf16 operands, pipe >= 90 %
     busy -- the chip then holds 1.3-1.7 GHz, not the 2.4 GHz behind the 2516.6 TFLOP/s nominal peak.  A separate
-    child process started after the timed region; None if the microbenchmark is not built."""
+    child process started BEFORE this process touches the GPU; None if the microbenchmark is not built."""
     import subprocess
     exe = os.path.join(ROOT, "tests", "micro", "simd_mix")
     if not os.path.exists(exe):
@@ -72,30 +110,154 @@ def power_limited_ceiling():
         return None
 
 
-def cpu_baseline(S, d, causal, budget_s=12.0):
-    """Naive fp32 attention (the oracle, a port of tests/main.cu:74-91 / check.py:19-21) on the host
-    cores, on a bounded sample: as many whole heads of the workload's (S, d) as fit ~budget_s."""
+def cpu_baseline_and_parity(Q, K, V, O, S, d, causal, budget_s=12.0):
+    """Naive fp32 attention (the oracle, a port of tests/main.cu:74-91 / check.py:19-21) on the host cores, on a bounded
+    sample of THIS run's tensors: as many whole heads of the workload as fit ~budget_s.  The same result is the checker
+    for the GPU output of those heads (`parity`).  Q, K, V, O: the rank's [heads, 1, S, d] device tensors."""
     import numpy as np
     import oracle
-    rng = np.random.default_rng(0)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity import parity_report
 
-    def timed(nh):
-        Q, K, V = (rng.standard_normal((1, nh, S, d), dtype=np.float32) for _ in range(3))
-        O = np.empty_like(Q)
+    def timed(h0, nh):
+        q, k, v = (np.ascontiguousarray(t[h0:h0 + nh].float().cpu().numpy().reshape(1, nh, S, d)) for t in (Q, K, V))
+        ref = np.empty_like(q)
         L = oracle.lib()
         t0 = time.perf_counter()
-        thr = L.oracle_attention_f32(oracle._p(Q), oracle._p(K), oracle._p(V), oracle._p(O), 1, nh, S, d,
+        thr = L.oracle_attention_f32(oracle._p(q), oracle._p(k), oracle._p(v), oracle._p(ref), 1, nh, S, d,
                                      float(1.0 / np.sqrt(d)), int(causal), 0)
-        return time.perf_counter() - t0, thr
+        return time.perf_counter() - t0, thr, ref
 
-    timed(1)                       # warm-up: thread pool start, first touch
-    t1, thr = timed(1)
-    nh = int(max(1, min(512, budget_s / max(t1, 1e-3))))
-    t, thr = timed(nh)
-    return {"value": round(flops_of(nh, S, d, causal) / t / 1e12, 5), "unit": "TFLOP/s", "cores": int(thr),
-            "kind": "port",
-            "sample": f"{nh} head(s) of the workload (S={S}, d={d}, causal={causal}), fp32 naive attention, "
+    heads = Q.shape[0]
+    timed(0, 1)                      # warm-up: thread pool start, first touch
+    t1, thr, _ = timed(0, 1)
+    nh = int(max(1, min(heads, budget_s / max(t1, 1e-3))))
+    h0 = heads - nh                  # the LAST heads of the slab (the first are the easy ones to get right)
+    t, thr, ref = timed(h0, nh)
+    got = O[h0:h0 + nh].float().cpu().numpy().reshape(1, nh, S, d)
+    base = {"value": round(flops_of(nh, S, d, causal) / t / 1e12, 5), "unit": "TFLOP/s", "cores": int(thr), "kind": "port",
+            "sample": f"the last {nh} head(s) of this run's tensors (S={S}, d={d}, causal={causal}), fp32 naive attention, "
                       f"{t:.2f} s wall, OpenMP over query rows"}
+    par = parity_report(got, ref)
+    par["checked"] = f"GPU output of the same {nh} head(s) against the oracle's result on the same (rounded) inputs"
+    return base, par
+
+
+def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps, warmup, dry, want_parity):
+    """One workload on this rank; returns the rank-0 record (None elsewhere)."""
+    B, H, S, d, causal, desc = WORKLOADS[workload]
+    if workload == "cfg4":           # fixed total problem, B*H split over the ranks (strong scaling)
+        lo, hi = shard.shard_heads(B * H, rank, world)
+        heads_local, scaling, total_heads = hi - lo, "strong", B * H
+    else:                            # same batch on every rank (weak scaling)
+        heads_local, scaling, total_heads = B * H, "weak", B * H * world
+    esz = 1 if workload == "cfg3" else 2
+    osz = 2 if args.out_dtype == "bf16" else 4
+    Q = K = V = O = None
+    if not dry:
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        shape = (heads_local, 1, S, d)   # the rank's slab as a dense [heads,1,S,d] tensor
+        in_dtype = torch.float8_e4m3fn if workload == "cfg3" else torch.bfloat16
+        Q, K, V = (torch.randn(shape, generator=g, device=dev, dtype=torch.float32).to(in_dtype) for _ in range(3))
+        O = torch.empty(shape, device=dev, dtype=torch.bfloat16 if args.out_dtype == "bf16" else torch.float32)
+    scale = 1.0 / d ** 0.5
+
+    def step():
+        if dry:
+            time.sleep(2e-4)
+        else:
+            fa.flash_attention(Q, K, V, O, scale=scale, is_causal=causal)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
+    def timed(n):
+        """n steps between barriers; (host seconds, HIP-event ms per step on the launch stream)"""
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        ev0 = ev1 = None
+        if not dry:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        if ev0:
+            ev0.record()             # same stream the kernel is launched on (torch's current stream)
+        for _ in range(n):
+            step()
+        if ev1:
+            ev1.record()
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        el = time.perf_counter() - t0
+        return el, (ev0.elapsed_time(ev1) / n if ev0 else el / n * 1e3)
+
+    # first touch (LDS limit raised, code object loaded), then the UNPRIMED figure: the same K steps from a device that has
+    # just come out of idle -- what a caller sees on its first few calls (clock ramp; reported beside `value`, never as it)
+    step(); sync()
+    el_cold, _ = timed(steps)
+    # Device priming (setup, untimed, before the W warmup steps): a GPU coming out of idle needs tens of milliseconds of
+    # work before its power state and clocks settle.  ~100 ms of the same launches, at most 3000.
+    t_p = time.perf_counter(); step(); step(); sync()
+    t_step = max((time.perf_counter() - t_p) / 2, 1e-6)
+    for _ in range(max(0, min(3000, int(0.1 / t_step)))):
+        step()
+    sync()
+    for _ in range(warmup):
+        step()
+    elapsed, kernel_ms = timed(steps)
+    elapsed = shard.reduce_max(elapsed)
+    el_cold = shard.reduce_max(el_cold)
+    kernel_ms_max = shard.reduce_max(kernel_ms)
+
+    ok = True
+    if not dry:                      # sanity: the output is finite and row 0 of a causal head equals V[0]
+        ok = bool(torch.isfinite(O.float()).all())
+        if causal:
+            ok = ok and bool(torch.allclose(O[:, :, 0].float(), V[:, :, 0].float(), rtol=1e-2, atol=1e-2))
+    ok_all = shard.reduce_sum(0.0 if ok else 1.0) == 0.0
+    if rank != 0:
+        return None
+
+    ms_per_step = elapsed / steps * 1e3
+    value = flops_of(total_heads, S, d, causal) / (ms_per_step * 1e-3) / 1e12
+    achieved = flops_of(heads_local, S, d, causal) / (kernel_ms_max * 1e-3) / 1e12
+    bound, peak, why = bound_for(workload)
+    traffic, prov = measured_traffic(workload) if world == 1 else (None, None)
+    algo_bytes = heads_local * S * d * (3 * esz + osz)
+    rec = {
+        "metric": METRIC if workload.startswith("cfg2") else f"fwd attention TFLOP/s/GPU ({desc}) + % MFMA peak",
+        "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+        "scaling": scaling, "vs_baseline": None, "dtype": "fp8_e4m3fn" if workload == "cfg3" else "bf16",
+        "data": "synthetic",
+        "config": {"workload": desc, "B": B, "H": H, "S": S, "d": d, "causal": causal,
+                   "out_dtype": args.out_dtype, "heads_per_gpu": heads_local,
+                   "flop_convention": "2*B*H*S^2*d causal / 4*B*H*S^2*d non-causal",
+                   "parallelism": f"batch x head shard over {world} GPU(s), no data-path collective"},
+        "value_per_gpu": round(value / world, 2),
+        "pct_of_bf16_mfma_peak": round(100.0 * value / (PEAK_BF16_TFLOPS * world), 2),
+        # the same K steps timed BEFORE the ~100 ms priming loop (device just out of idle): not the metric, the caveat
+        "value_unprimed": round(flops_of(total_heads, S, d, causal) / (el_cold / steps) / 1e12, 2),
+        # SURVEY.md section 8d: causal FLOPs count only the unmasked half; the full-count figure alongside, labelled
+        "value_if_masked_half_counted_too": round(value * (2.0 if causal else 1.0), 2),
+        "output_ok": ok_all,
+        "roofline": {"bound": bound, "achieved": round(achieved, 2), "peak": round(peak, 1),
+                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "bound_derivation": why,
+                     "frac_of_nominal_bf16_mfma_peak": round(achieved / PEAK_BF16_TFLOPS, 4),
+                     "traffic": traffic, "traffic_provenance": prov,
+                     "kernel": "fa::fwd_mfma_kernel", "kernel_ms": round(kernel_ms_max, 5),
+                     "algorithmic_hbm_bytes": algo_bytes,
+                     "algorithmic_hbm_GBps": round(algo_bytes / (kernel_ms_max * 1e-3) / 1e9, 1)},
+    }
+    if dry:
+        rec["dry_run"] = True
+    if want_parity and not dry:
+        rec["cpu_baseline"], rec["parity"] = cpu_baseline_and_parity(Q, K, V, O, S, d, causal)
+    return rec
 
 
 def main():
@@ -106,13 +268,19 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the power-limited-ceiling microbenchmark")
+    ap.add_argument("--no-cfg4", action="store_true", help="N > 1: skip the cfg4 strong-scaling sub-record")
     ap.add_argument("--out-dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: no launches, no measurements -- the line's structure only")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     # The ceiling microbenchmark is a separate GPU program: run it as a child BEFORE this process touches the GPU
     # (no exec from a process that has initialised HIP).  Single-GPU runs only.
     ceil = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_ceiling and args.workload != "cfg3":
+    if world == 1 and not args.no_ceiling and not args.dry_run and args.workload != "cfg3":
         ceil = power_limited_ceiling()
 
     import torch
@@ -121,112 +289,34 @@ def main():
     fa = entry.load_package()
     from flash_attention_cuda_c_amd import shard
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    n_gpus = world
+    dev = None
+    if args.dry_run:
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    B, H, S, d, causal, desc = WORKLOADS[args.workload]
-    if args.workload == "cfg4":     # fixed total problem, B*H split over the ranks (strong scaling)
-        lo, hi = shard.shard_heads(B * H, rank, world)
-        heads_local, scaling = hi - lo, "strong"
-        total_heads = B * H
-    else:                            # same batch on every rank (weak scaling)
-        heads_local, scaling = B * H, "weak"
-        total_heads = B * H * world
-
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    shape = (heads_local, 1, S, d)   # the rank's slab as a dense [heads,1,S,d] tensor
-    in_dtype = torch.float8_e4m3fn if args.workload == "cfg3" else torch.bfloat16
-    Q, K, V = (torch.randn(shape, generator=g, device=dev, dtype=torch.float32).to(in_dtype) for _ in range(3))
-    O = torch.empty(shape, device=dev, dtype=torch.bfloat16 if args.out_dtype == "bf16" else torch.float32)
-    scale = 1.0 / d ** 0.5
-
-    def step():
-        fa.flash_attention(Q, K, V, O, scale=scale, is_causal=causal)
-
-    # Device priming (setup, untimed, before the W warmup steps): a GPU coming out of idle needs tens of milliseconds
-    # of work before its power state and clocks settle -- with a small W the timed steps would otherwise run on the
-    # ramp (measured: 855 instead of ~980 TFLOP/s at W=5, K=20).  ~100 ms of the same launches, at most 3000.
-    step(); torch.cuda.synchronize()
-    t_p = time.perf_counter(); step(); step(); torch.cuda.synchronize()
-    t_step = max((time.perf_counter() - t_p) / 2, 1e-6)
-    for _ in range(max(0, min(3000, int(0.1 / t_step)))):
-        step()
-    torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                     # same stream the kernel is launched on (torch's current stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    elapsed = shard.reduce_max(elapsed)
-    kernel_ms_max = shard.reduce_max(kernel_ms)
-
-    # sanity: the output is finite and row 0 of a causal head equals V[0]
-    ok = bool(torch.isfinite(O.float()).all())
-    if causal:
-        ok = ok and bool(torch.allclose(O[:, :, 0].float(), V[:, :, 0].float(), rtol=1e-2, atol=1e-2))
-    ok_all = shard.reduce_sum(0.0 if ok else 1.0) == 0.0
-
+    line = run_workload(fa, shard, torch, dist, args, args.workload, world, rank, dev, args.steps, args.warmup, args.dry_run,
+                        want_parity=world == 1 and not args.no_cpu_baseline)
+    if rank == 0 and ceil:
+        a = line["roofline"]["achieved"]
+        line["roofline"]["power_limited"] = dict(
+            ceil, frac_of_mfma_only=round(a / ceil["mfma_only_random_bf16_tflops"], 4),
+            frac_of_attention_mix=round(a / ceil["attention_mix_random_bf16_tflops"], 4))
+    # N > 1: BASELINE configs[4] itself, its 2048 heads split over the ranks (the driver never passes --workload cfg4)
+    if world > 1 and not args.no_cfg4 and args.workload != "cfg4":
+        sub = run_workload(fa, shard, torch, dist, args, "cfg4", world, rank, dev, max(2, min(5, args.steps)), 1, args.dry_run, False)
+        if rank == 0:
+            line["cfg4"] = {k: sub[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config",
+                                                 "value_per_gpu", "pct_of_bf16_mfma_peak", "output_ok")}
+            line["cfg4"]["roofline"] = {k: sub["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms")}
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        flops_job = flops_of(total_heads, S, d, causal)
-        value = flops_job / (ms_per_step * 1e-3) / 1e12
-        flops_launch = flops_of(heads_local, S, d, causal)
-        achieved = flops_launch / (kernel_ms_max * 1e-3) / 1e12
-        # fp8 inputs: QK^T (half the FLOPs) runs on the block-scaled MX MFMA at twice the bf16 rate, P.V on the bf16
-        # MFMA: the bound is the time-weighted mix 1 / (0.5/5033.2 + 0.5/2516.6) = 3355.5 TFLOP/s
-        peak = 1.0 / (0.5 / (2 * PEAK_BF16_TFLOPS) + 0.5 / PEAK_BF16_TFLOPS) if args.workload == "cfg3" else PEAK_BF16_TFLOPS
-        line = {
-            "metric": "fwd attention TFLOP/s (bf16, seq=4096, d=128) + % MFMA peak" if args.workload.startswith("cfg2")
-                      else "fwd attention TFLOP/s",
-            "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": "fp8_e4m3fn" if args.workload == "cfg3" else "bf16",
-            "data": "synthetic",
-            "config": {"workload": desc, "B": B, "H": H, "S": S, "d": d, "causal": causal,
-                       "out_dtype": args.out_dtype, "heads_per_gpu": heads_local,
-                       "flop_convention": "2*B*H*S^2*d causal / 4*B*H*S^2*d non-causal",
-                       "parallelism": f"batch x head shard over {n_gpus} GPU(s), no data-path collective"},
-            "pct_of_bf16_mfma_peak": round(100.0 * value / (PEAK_BF16_TFLOPS * n_gpus), 2),
-            # causal FLOPs count only the unmasked half; the full-count figure alongside, labelled
-            "value_if_masked_half_counted_too": round(value * (2.0 if causal else 1.0), 2),
-            "output_ok": ok_all,
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
-                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": measured_traffic(args.workload) if n_gpus == 1 else None,
-                         "kernel": "fa::fwd_mfma_kernel", "kernel_ms": round(kernel_ms_max, 5),
-                         "algorithmic_hbm_bytes": heads_local * S * d * (3 * Q.element_size() + O.element_size()),
-                         "algorithmic_hbm_GBps": round(heads_local * S * d * (3 * Q.element_size() + O.element_size())
-                                                       / (kernel_ms_max * 1e-3) / 1e9, 1)},
-        }
-        if ceil:
-            line["roofline"]["power_limited"] = dict(
-                ceil, frac_of_mfma_only=round(achieved / ceil["mfma_only_random_bf16_tflops"], 4),
-                frac_of_attention_mix=round(achieved / ceil["attention_mix_random_bf16_tflops"], 4))
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(S, d, causal)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -153,11 +153,20 @@ static hipError_t launch_mfma(const Params& p, const fa_launch_plan& plan, hipSt
     return hipGetLastError();
 }
 
+template <int D, bool CAUSAL, int ESZ, bool PAD, bool LSE>
+static hipError_t launch_mfma_out2(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
+    if (o_dtype == FA_DTYPE_F32) return launch_mfma<ProdCfg<D, CAUSAL, float, ESZ, false, PAD, LSE>>(p, plan, st);
+    if (o_dtype == FA_DTYPE_BF16) return launch_mfma<ProdCfg<D, CAUSAL, __bf16, ESZ, false, PAD, LSE>>(p, plan, st);
+    return launch_mfma<ProdCfg<D, CAUSAL, _Float16, ESZ, false, PAD, LSE>>(p, plan, st);
+}
+// bf16 inputs: a call that also wants the LSE runs the instantiation that sums the unrounded weights (computers16.hip.h);
+// the fp8 kernels (32x32x16 engine) sum unrounded weights anyway
 template <int D, bool CAUSAL, int ESZ, bool PAD = false>
 static hipError_t launch_mfma_out(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
-    if (o_dtype == FA_DTYPE_F32) return launch_mfma<ProdCfg<D, CAUSAL, float, ESZ, false, PAD>>(p, plan, st);
-    if (o_dtype == FA_DTYPE_BF16) return launch_mfma<ProdCfg<D, CAUSAL, __bf16, ESZ, false, PAD>>(p, plan, st);
-    return launch_mfma<ProdCfg<D, CAUSAL, _Float16, ESZ, false, PAD>>(p, plan, st);
+    if constexpr (ESZ == 2) {
+        if (p.lse) return launch_mfma_out2<D, CAUSAL, ESZ, PAD, true>(p, plan, o_dtype, st);
+    }
+    return launch_mfma_out2<D, CAUSAL, ESZ, PAD, false>(p, plan, o_dtype, st);
 }
 
 template <class Cfg>

@@ -26,7 +26,9 @@
 //                 COMPLETE row sum (all four lane quarters) lands in every lane: no v_add_f32 per score element (the
 //                 kernel is bound by the SIMD's shared instruction-issue port, where 32 adds cost 128 cycles per wave and
 //                 tile and 4 MFMAs 32), no cross-lane reduction at the end, and the normaliser sums exactly the
-//                 bf16-rounded weights the numerator uses (V = 1 gives O = 1 exactly).
+//                 bf16-rounded weights the numerator uses (V = 1 gives O = 1 exactly).  The kernels that also return the
+//                 LSE (C::SUM_MFMA = false) keep the fp32 sum of the UNROUNDED weights by v_add_f32 instead: the
+//                 log-sum-exp is then exact to fp32 rounding (the bf16-rounded sum is off by up to 2^-9 relative).
 //
 // Slots: SA = 2*KG*KS (QK^T of tile t+1) + SB = 2*2*D/16 (P.V of tile t) MFMAs per tile, one per slot, fenced by
 // sched_barrier(0).  Score element E (0..31) = (k-step kk = E/16, query group qg = (E/8)%2, j = E%8) goes to overall slot
@@ -65,12 +67,13 @@ struct WaveCompute16 {
     u32x4 qf[QG][KS];   // Q fragments
     f32x4 o[QG][DG];    // O^T accumulators: row = d, col = query
     float m[QG];        // reference max used for exponentiation (scaled, log2 domain)
-    f32x4 lsum[QG];     // row sums of the bf16-rounded weights, from the ONES.P^T MFMAs (all four registers hold the same value)
+    f32x4 lsum[QG];     // C::SUM_MFMA: row sums of the bf16-rounded weights, from the ONES.P^T MFMAs (all four registers equal)
+    float l[QG];        // !C::SUM_MFMA (the LSE variants): fp32 sum of the UNROUNDED weights of this lane's quarter of the keys
     // ---- per-tile scratch ----
     u32x4 kf[NPRE];
     bf16x8 vf[VPRE + 1];
     uint32_t pw[QG][2][4];   // P(t) as packed bf16 pairs: [query group][k-step][word w = elements 2w, 2w+1]
-    float mx_a[QG], mx_b[QG], p_even;
+    float mx_a[QG], mx_b[QG], p_even, sum_a[QG], sum_b[QG];
     bool need;
     unsigned long long t_mid = 0, t_end = 0;   // STAMP builds only
 
@@ -83,7 +86,13 @@ struct WaveCompute16 {
             for (int i = 0; i < DG; ++i) o[qg][i] = f32x4{0.f, 0.f, 0.f, 0.f};
             m[qg] = -INFINITY;
             lsum[qg] = f32x4{0.f, 0.f, 0.f, 0.f};
+            l[qg] = 0.f;
         }
+    }
+    // complete row sum of query group qg in every lane
+    __device__ __forceinline__ float row_sum_total(int qg) const {
+        if constexpr (C::SUM_MFMA) return lsum[qg][0];
+        else return sum_all_quarters(l[qg]);
     }
     __device__ __forceinline__ static bf16x8 ones_frag() {
         u32x4 v = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
@@ -203,8 +212,16 @@ struct WaveCompute16 {
     __device__ __forceinline__ void exp_elem(const Scores16& cur, float c) {
         constexpr int kk = E / 16, qg = (E / 8) % 2, j = E % 8, kg = 2 * kk + (j >> 2), reg = j & 3;
         const float p = fast_exp2(fmaf(cur.s[kg][qg][reg], c, -m[qg]));
-        if constexpr (j & 1) pw[qg][kk][j >> 1] = pack_bf16(p_even, p);
-        else p_even = p;
+        if constexpr (!C::SUM_MFMA) {
+            if constexpr (j & 1) sum_b[qg] += p;
+            else sum_a[qg] += p;
+        }
+        if constexpr (j & 1) {
+            pw[qg][kk][j >> 1] = pack_bf16(p_even, p);
+            if constexpr (!C::SUM_MFMA) asm volatile("" : "+v"(sum_a[qg]), "+v"(sum_b[qg]));   // keep the adds in this slot (hipcc sinks them)
+        } else {
+            p_even = p;
+        }
     }
     template <int SLOT, int E = 0>
     __device__ __forceinline__ void exp_slot(const Scores16& cur, float c) {
@@ -277,7 +294,7 @@ struct WaveCompute16 {
         if constexpr (J < SB) {
             constexpr int v = J / QG, qg = J % QG, kk = v / DG, dg = v % DG;
             o[qg][dg] = mfma_16x16x32(vf[v % (VPRE + 1)], p_frag(qg, kk), o[qg][dg]);
-            if constexpr (dg == 1) lsum[qg] = mfma_16x16x32(ones_frag(), p_frag(qg, kk), lsum[qg]);   // row sums of this k-step
+            if constexpr (C::SUM_MFMA && dg == 1) lsum[qg] = mfma_16x16x32(ones_frag(), p_frag(qg, kk), lsum[qg]);   // row sums of this k-step
             if constexpr (qg == QG - 1 && v + VPRE < NV) {
                 constexpr int vn = v + VPRE;
                 vf[vn % (VPRE + 1)] = v_frag(v_cur, vbase, vn / DG, vn % DG);
@@ -300,7 +317,10 @@ struct WaveCompute16 {
                                               lds_ptr = nullptr) {
         static_assert(!LAST, "the 16x16x32 path has no separate last-tile step");
 #pragma unroll
-        for (int qg = 0; qg < QG; ++qg) mx_a[qg] = mx_b[qg] = -INFINITY;
+        for (int qg = 0; qg < QG; ++qg) {
+            mx_a[qg] = mx_b[qg] = -INFINITY;
+            sum_a[qg] = sum_b[qg] = 0.f;
+        }
         zero(nxt);
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
@@ -309,6 +329,10 @@ struct WaveCompute16 {
         if constexpr (C::STAMP) t_mid = cycle_stamp();
         slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
+        if constexpr (!C::SUM_MFMA) {
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) l[qg] += sum_a[qg] + sum_b[qg];
+        }
         // ONE rescale site (two sites that both multiply O make hipcc copy all accumulator registers per tile)
         if (has_next && mask_next) {
             mask(nxt, kv0_next, q_row0, S, lane);
@@ -326,6 +350,7 @@ struct WaveCompute16 {
                     const float alpha = fast_exp2(m[qg] - mn);
                     m[qg] = mn;
                     lsum[qg] *= alpha;
+                    l[qg] *= alpha;
 #pragma unroll
                     for (int i = 0; i < DG; ++i) o[qg][i] *= alpha;
                 }
@@ -338,7 +363,7 @@ struct WaveCompute16 {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
-            acc[0] = fmaf(lsum[qg][0], 0.f, acc[0]);
+            acc[0] = fmaf(C::SUM_MFMA ? lsum[qg][0] : l[qg], 0.f, acc[0]);
 #pragma unroll
             for (int i = 0; i < DG; ++i)
 #pragma unroll
@@ -361,7 +386,7 @@ struct WaveCompute16 {
                                             int orow_bytes = D * (int)sizeof(OutT)) {
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
-            const float l_tot = lsum[qg][0];
+            const float l_tot = row_sum_total(qg);
             store_lse(lse_head, l_tot, qg, row0, S, lane);
             const float inv = 1.0f / l_tot;
             const int qi = row0 + 16 * qg + (lane & 15);
@@ -398,7 +423,7 @@ struct WaveCompute16 {
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
             const int q = 16 * qg + (lane & 15);
-            const float l_tot = lsum[qg][0];
+            const float l_tot = row_sum_total(qg);
             store_lse(lse_head, l_tot, qg, row0, S, lane);
             const float inv = 1.0f / l_tot;
 #pragma unroll
@@ -431,7 +456,7 @@ struct WaveCompute16 {
         float inv[QG];
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
-            const float l_tot = lsum[qg][0];
+            const float l_tot = row_sum_total(qg);
             store_lse(lse_head, l_tot, qg, row0, S, lane);
             inv[qg] = 1.0f / l_tot;
         }

@@ -49,6 +49,8 @@ struct Opt {
     int mxqk = -1;               // fp8 inputs: QK^T on the block-scaled 32x32x64 MFMA with unit scales (-1: on iff fp8)
     int m16 = -1;                // both products on v_mfma_f32_16x16x32_bf16 (computers16.hip.h) instead of 32x32x16: the chip holds
                                  // a higher clock on that shape (power).  -1: on for bf16 inputs with r = 1
+    int sum_mfma = -1;           // 16x16x32 engine: row sums from ONES.P^T MFMAs (sums the bf16-rounded weights) instead of one v_add_f32
+                                 // per score.  -1: on (the library turns it off in the kernels that return the LSE)
     // ---- rejected by measurement, kept as arms of the tuner (numbers: causal / non-causal headline shape) ----
     int wg = 1;                  // K / V^T fragments consumed per s_waitcnt (1: hipcc's one wait per MFMA; 2: -2 %, 4: 0 %)
     int ring = 3;                // LDS ring slots: 3 (tile t+2 staged in iteration t) or 4 (tile t+3: the next tile's first K
@@ -79,6 +81,7 @@ struct KernelCfg {
     static constexpr bool MXQK = O.mxqk < 0 ? ESZ_ == 1 : O.mxqk != 0;
     static constexpr bool M16 = (O.m16 < 0 ? true : O.m16 != 0) && ESZ_ == 2 && O.r == 1 && !O.asm_mfma && O.ring == 3 && !O.skip_last_qk &&
                                 !O.pk && !O.dot2 && O.wg == 1;
+    static constexpr bool SUM_MFMA = M16 && (O.sum_mfma < 0 ? true : O.sum_mfma != 0);
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
     static constexpr int NWAVES = 8 / O.r;           // waves per workgroup (256 query rows)
@@ -92,8 +95,8 @@ struct KernelCfg {
 };
 
 // What the library launches: the defaults of Opt.
-template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false, bool PAD = false>
-using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, Opt{.stamp = STAMP, .pad = PAD}>;
+template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false, bool PAD = false, bool LSE = false>
+using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, Opt{.stamp = STAMP, .pad = PAD, .sum_mfma = LSE ? 0 : -1}>;
 
 // The per-wave compute engine of a configuration: 16x16x32 MFMAs (computers16.hip.h) or 32x32x16 (computers.hip.h).
 template <class C>

@@ -13,7 +13,10 @@ import sys
 csv.field_size_limit(1 << 30)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-ALGO = {"cfg2": 8 * 16 * 4096 * 128 * 2 * 4, "cfg2nc": 8 * 16 * 4096 * 128 * 2 * 4, "cfg1": 4 * 8 * 2048 * 64 * 2 * 4}
+ALGO = {"cfg2": 8 * 16 * 4096 * 128 * 2 * 4, "cfg2nc": 8 * 16 * 4096 * 128 * 2 * 4, "cfg1": 4 * 8 * 2048 * 64 * 2 * 4,
+        "cfg3": 1 * 16 * 16384 * 128 * (3 * 1 + 2)}
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import provenance  # noqa: E402
 
 
 def one(pattern):
@@ -49,7 +52,7 @@ def main():
         wr = 1024.0 * sum(v for v, _ in write) / len(write)
         json.dump({"workload": wl, "launches": len(fetch), "note": "FETCH_SIZE doubled (gfx950), counters in KiB, separate --pmc passes",
                    "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "traffic_bytes_per_launch": rd + wr,
-                   "algorithmic_bytes_per_launch": ALGO.get(wl)}, open(os.path.join(OUT, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+                   "algorithmic_bytes_per_launch": ALGO.get(wl), "csrc_sha256": provenance.csrc_sha256()}, open(os.path.join(OUT, f"{tag}_hbm_traffic.json"), "w"), indent=1)
     sq = counters(tag, "sq")
     if sq:
         n = len(sq["GRBM_GUI_ACTIVE"])

@@ -216,5 +216,11 @@ int main(int argc, char** argv) {
     run<16, 16, 16, 8, 0, 0, false, true, 2, false, true>("M16 RANDOM: softmax mix, every slot waits for an LDS operand read 2 slots earlier", d);
     run<0, 0, 0, 0, 0, 0, false, false, 0, false, true>("M16 constant operands: MFMA only", d);
     run<16, 16, 16, 8, 8, 16, false, false, 0, false, true>("M16 constant operands: softmax mix + LDS mix", d);
+    // the 16x16x32 kernels' own mixes per slot (= 2 MFMAs): row sums come from an MFMA, so no v_add
+    run<16, 16, 0, 8, 8, 16, false, true, 0, false, true>("M16 RANDOM: kernel mix, 32 rows/wave (1 fma + 1 exp + .5 cvt + .5 b128 + 1 tr)", d);
+    run<16, 16, 0, 8, 4, 8, false, true, 0, false, true>("M16 RANDOM: kernel mix, 64 rows/wave (half the LDS reads)", d);
+    run<16, 16, 0, 8, 2, 4, false, true, 0, false, true>("M16 RANDOM: kernel mix, 128 rows/wave-equivalent (quarter LDS reads)", d);
+    run<16, 16, 0, 8, 0, 0, false, true, 0, false, true>("M16 RANDOM: kernel mix without LDS reads", d);
+    run<0, 16, 0, 8, 8, 16, false, true, 0, false, true>("M16 RANDOM: kernel mix without the exponent fma", d);
     return 0;
 }

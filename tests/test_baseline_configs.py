@@ -98,9 +98,11 @@ def test_baseline_cfg4_offsets():
     # rank 7's slab of the 8-way shard, as its own dense problem == the same heads of the full run, bit for bit
     lo, hi = fa.shard_range(BH, 7, 8)
     assert (lo, hi) == (1792, 2048)
-    Os = fa.flash_attention(Q[lo:hi], K[lo:hi], V[lo:hi], is_causal=False)
+    # (same entry point as the full run: a call that also returns the LSE sums the unrounded weights, one that does not
+    #  takes its row sums from an MFMA over the bf16-rounded ones -- the two differ in the last bit)
+    Os, lse_s = fa.flash_attention(Q[lo:hi], K[lo:hi], V[lo:hi], is_causal=False, return_lse=True)
     torch.cuda.synchronize()
-    assert torch.equal(Os, O[lo:hi])
+    assert torch.equal(Os, O[lo:hi]) and torch.equal(lse_s, lse[lo:hi])
     del Os
     # causal, last heads only (the slab again): last row block of the last head against the oracle
     Oc = fa.flash_attention(Q[lo:hi], K[lo:hi], V[lo:hi], is_causal=True, out_dtype=torch.float32)

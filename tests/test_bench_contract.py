@@ -31,7 +31,71 @@ def test_flop_convention_and_peak():
     assert bench.PEAK_BF16_TFLOPS == 256 * 4 * 1024 * 2.4e9 / 1e12 == 2516.5824 or abs(bench.PEAK_BF16_TFLOPS - 2516.58) < 0.05
 
 
-def test_committed_traffic_measurement_is_found():
-    t = bench.measured_traffic("cfg2")
-    assert isinstance(t, int) and 4 * 8 * 16 * 4096 * 128 * 2 <= t < 2 * 4 * 8 * 16 * 4096 * 128 * 2   # >= algorithmic, < 2x
-    assert bench.measured_traffic("no-such-workload") is None
+def test_traffic_is_reported_only_with_matching_provenance(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed PMC run, and only while the kernel sources are the ones it was taken on."""
+    import provenance
+    now = provenance.csrc_sha256()
+    assert len(now) == 64 and now == provenance.csrc_sha256()
+    t, prov = bench.measured_traffic("no-such-workload")
+    assert t is None and prov["file"] is None
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (prof / "r02_hbm_traffic_cfg2.json").write_text(json.dumps({"traffic_bytes_per_launch": 600000000.0, "csrc_sha256": now}))
+    t, prov = bench.measured_traffic("cfg2")
+    assert t == 600000000 and prov["matches_built_sources"] is True
+    (prof / "r02_hbm_traffic_cfg2.json").write_text(json.dumps({"traffic_bytes_per_launch": 600000000.0, "csrc_sha256": "0" * 64}))
+    t, prov = bench.measured_traffic("cfg2")
+    assert t is None and prov["matches_built_sources"] is False
+
+
+def test_metric_string_and_bounds():
+    assert bench.METRIC == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    b, peak, _ = bench.bound_for("cfg2")
+    assert b == "mfma" and abs(peak - 2516.6) < 0.1
+    b, peak, _ = bench.bound_for("cfg1")          # d = 64: vector issue (736 cycles) outweighs the MFMA pipe (576) per wave-tile
+    assert b == "valu" and abs(peak - 2516.6 * 512 / 736) < 0.1
+    b, peak, _ = bench.bound_for("cfg3")
+    assert b == "mfma" and abs(peak - 3355.5) < 0.1
+
+
+def _bench_rank(rank, world, port, q):
+    import io
+    import contextlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--dry-run", "--no-ceiling"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    q.put((rank, buf.getvalue()))
+
+
+def test_two_rank_dry_run_line_carries_the_cfg4_sub_record():
+    """world_size 2 over gloo, no GPU: the N > 1 line's structure -- weak-scaling headline + the cfg4 strong-scaling sub-record
+    (BASELINE configs[4]: 2048 heads split over the ranks)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert outs[1].strip() == ""                               # only rank 0 prints
+    lines = [l for l in outs[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["scaling"] == "weak" and line["metric"] == bench.METRIC
+    assert line["config"]["heads_per_gpu"] == 128 and line["steps"] == 3
+    sub = line["cfg4"]
+    assert sub["scaling"] == "strong" and sub["n_gpus"] == 2 and sub["config"]["heads_per_gpu"] == 1024
+    assert (sub["config"]["B"], sub["config"]["H"], sub["config"]["S"], sub["config"]["d"]) == (64, 32, 8192, 128)
+    assert {"bound", "achieved", "peak", "frac"} <= set(sub["roofline"])

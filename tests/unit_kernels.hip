@@ -15,6 +15,7 @@
 // Prints one line per test, "N test(s) failed" at the end, exit status = number of failures.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -408,12 +409,116 @@ static void test_lds_image16() {
     HIP_CHECK(hipFree(dk)); HIP_CHECK(hipFree(dv)); HIP_CHECK(hipFree(dimg)); HIP_CHECK(hipFree(dkf)); HIP_CHECK(hipFree(dvf));
 }
 
+// ------------------------------------------------------------------------------------------------ (3) fp8 MFMA accumulation
+// How exactly does gfx950's fp8 MFMA sum its products?  (A measurement, not a pass/fail test: the fp8 LSE bound of
+// tests/test_fuzz_slice.py is derived from the figure printed here.)  One wave computes D = A.B over K = 128 as the kernel
+// does -- two chained v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales -- on e4m3fn values drawn as round(N(0, sigma));
+// the host forms the exact sums in double.  Printed: max over the 32x32 outputs and all trials of |D - exact| / sum_k |a_k b_k|
+// (the natural scale of a summation error) for the fp8 instruction, and for the bf16 32x32x16 instruction on the SAME values.
+__global__ void fp8_accum_probe(const uint8_t* A, const uint8_t* B, float* out_mx, float* out_bf16) {
+    // A: [32 rows][128 k] e4m3 bytes, B: [128 k][32 cols] e4m3 bytes (row-major)
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    f32x16 c;
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    for (int step = 0; step < 2; ++step) {
+        uint8_t ab[32], bb[32];
+        for (int j = 0; j < 32; ++j) {
+            const int k = 64 * step + 32 * h + j;
+            ab[j] = A[r * 128 + k];
+            bb[j] = B[k * 32 + r];
+        }
+        u32x4 alo, ahi, blo, bhi;
+        for (int w = 0; w < 4; ++w) {
+            alo[w] = ab[4 * w] | (ab[4 * w + 1] << 8) | (ab[4 * w + 2] << 16) | ((uint32_t)ab[4 * w + 3] << 24);
+            ahi[w] = ab[16 + 4 * w] | (ab[17 + 4 * w] << 8) | (ab[18 + 4 * w] << 16) | ((uint32_t)ab[19 + 4 * w] << 24);
+            blo[w] = bb[4 * w] | (bb[4 * w + 1] << 8) | (bb[4 * w + 2] << 16) | ((uint32_t)bb[4 * w + 3] << 24);
+            bhi[w] = bb[16 + 4 * w] | (bb[17 + 4 * w] << 8) | (bb[18 + 4 * w] << 16) | ((uint32_t)bb[19 + 4 * w] << 24);
+        }
+        c = mfma_32x32x64_fp8_unit_scale(alo, ahi, blo, bhi, c);
+    }
+    for (int i = 0; i < 16; ++i) out_mx[acc_row(i, h) * 32 + r] = c[i];
+    // the same values, widened exactly to bf16, through 8 chained 32x32x16 bf16 MFMAs
+    f32x16 cb;
+    for (int i = 0; i < 16; ++i) cb[i] = 0.f;
+    for (int step = 0; step < 8; ++step) {
+        uint32_t aw[4], bw[4];
+        for (int w = 0; w < 4; ++w) {
+            const int k0 = 16 * step + 8 * h + 2 * w;
+            const u32x4 a4 = fp8x8_to_bf16x8(A[r * 128 + k0] | ((uint32_t)A[r * 128 + k0 + 1] << 8), 0);
+            const u32x4 b4 = fp8x8_to_bf16x8(B[k0 * 32 + r] | ((uint32_t)B[(k0 + 1) * 32 + r] << 8), 0);
+            aw[w] = a4[0];
+            bw[w] = b4[0];
+        }
+        u32x4 a = {aw[0], aw[1], aw[2], aw[3]}, b = {bw[0], bw[1], bw[2], bw[3]};
+        cb = mfma_32x32x16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), cb);
+    }
+    for (int i = 0; i < 16; ++i) out_bf16[acc_row(i, h) * 32 + r] = cb[i];
+}
+
+static float e4m3fn_decode(uint8_t b) {
+    const int sgn = b >> 7, e = (b >> 3) & 15, m = b & 7;
+    float v = e == 0 ? std::ldexp((float)m, -9) : std::ldexp(1.0f + m / 8.0f, e - 7);
+    return sgn ? -v : v;
+}
+static uint8_t e4m3fn_encode_nearest(float x) {   // brute force over the 254 finite codes
+    uint8_t best = 0;
+    float bd = 1e30f;
+    for (int c = 0; c < 256; ++c) {
+        if ((c & 0x7f) == 0x7f) continue;
+        const float d = std::fabs(e4m3fn_decode((uint8_t)c) - x);
+        if (d < bd) { bd = d; best = (uint8_t)c; }
+    }
+    return best;
+}
+
+static void measure_fp8_accumulation() {
+    uint8_t *dA, *dB;
+    float *dmx, *dbf;
+    HIP_CHECK(hipMalloc(&dA, 32 * 128)); HIP_CHECK(hipMalloc(&dB, 128 * 32));
+    HIP_CHECK(hipMalloc(&dmx, 32 * 32 * 4)); HIP_CHECK(hipMalloc(&dbf, 32 * 32 * 4));
+    std::vector<uint8_t> hA(32 * 128), hB(128 * 32);
+    std::vector<float> mx(32 * 32), bf(32 * 32);
+    uint64_t state = 0x1234567ull;
+    auto rnd = [&]() { state = state * 6364136223846793005ull + 1442695040888963407ull; return (double)(state >> 11) / 9007199254740992.0; };
+    auto gauss = [&]() { return std::sqrt(-2.0 * std::log(rnd() + 1e-300)) * std::cos(6.283185307179586 * rnd()); };
+    for (double sigma : {1.0, 3.0, 12.0}) {
+        double eps_mx = 0, eps_bf = 0, rel_mx = 0;
+        for (int trial = 0; trial < 40; ++trial) {
+            for (auto& x : hA) x = e4m3fn_encode_nearest((float)(sigma * gauss()));
+            for (auto& x : hB) x = e4m3fn_encode_nearest((float)(sigma * gauss()));
+            HIP_CHECK(hipMemcpy(dA, hA.data(), hA.size(), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(dB, hB.data(), hB.size(), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(fp8_accum_probe, dim3(1), dim3(64), 0, nullptr, dA, dB, dmx, dbf);
+            HIP_CHECK(hipDeviceSynchronize());
+            HIP_CHECK(hipMemcpy(mx.data(), dmx, mx.size() * 4, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(bf.data(), dbf, bf.size() * 4, hipMemcpyDeviceToHost));
+            for (int i = 0; i < 32; ++i)
+                for (int j = 0; j < 32; ++j) {
+                    double ex = 0, ab = 0;
+                    for (int k = 0; k < 128; ++k) {
+                        const double p = (double)e4m3fn_decode(hA[i * 128 + k]) * (double)e4m3fn_decode(hB[k * 32 + j]);
+                        ex += p;
+                        ab += std::fabs(p);
+                    }
+                    eps_mx = std::max(eps_mx, std::fabs(mx[i * 32 + j] - ex) / ab);
+                    eps_bf = std::max(eps_bf, std::fabs(bf[i * 32 + j] - ex) / ab);
+                    if (std::fabs(ex) > 0.05 * ab) rel_mx = std::max(rel_mx, std::fabs(mx[i * 32 + j] - ex) / std::fabs(ex));
+                }
+        }
+        printf("MEASURE fp8 accumulation, K=128, sigma=%4.1f: max |D-exact| / sum|a_k b_k|:  MX fp8 MFMA %.3e (2^%.2f)   bf16 MFMA on the same values %.3e (2^%.2f)   "
+               "[fp8: max |D-exact|/|exact| where |exact| > 5%% of sum|ab|: %.3e]\n",
+               sigma, eps_mx, std::log2(eps_mx), eps_bf, eps_bf > 0 ? std::log2(eps_bf) : -99.0, rel_mx);
+    }
+    HIP_CHECK(hipFree(dA)); HIP_CHECK(hipFree(dB)); HIP_CHECK(hipFree(dmx)); HIP_CHECK(hipFree(dbf));
+}
+
 int main() {
     test_mfma_layouts();
     test_lds_image<128>();
     test_lds_image<64>();
     test_lds_image16<128>();
     test_lds_image16<64>();
+    measure_fp8_accumulation();
     printf("%d test(s) failed\n", g_fail);
     return g_fail;
 }
