@@ -4,7 +4,9 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     := gfx950
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -fno-slp-vectorize
 LIB      := $(PKG)/libflash_attention.so
-KSRC     := $(PKG)/csrc/FlashAttention.hip
+# the library's translation units: the C ABI + one unit per group of kernel instantiations (they compile in parallel)
+KSRC     := $(wildcard $(PKG)/csrc/*.hip)
+KOBJ     := $(patsubst $(PKG)/csrc/%.hip,build/obj/%.o,$(KSRC))
 KHDR     := $(wildcard $(PKG)/csrc/*.h) $(PKG)/helpers.hpp include/flash_attention.h
 
 # `all` = the product, its C++ harness and driver, the oracle, the microbenchmarks bench.py uses (about 1.5 min with -j4).
@@ -15,8 +17,12 @@ tune: tests/fa_tune
 
 lib: $(LIB)
 
-$(LIB): $(KSRC) $(KHDR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(KSRC)
+build/obj/%.o: $(PKG)/csrc/%.hip $(KHDR)
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(KOBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(KOBJ)
 
 oracle: oracle/liboracle_attention.so
 
@@ -47,7 +53,7 @@ tests/micro/%: tests/micro/%.hip
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++20 -o $@ $<
 
 asm: $(KSRC) $(KHDR)
-	mkdir -p build && $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/FlashAttention.s $(KSRC)
+	mkdir -p build && $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/inst_bf16_d128.s $(PKG)/csrc/inst_bf16_d128.hip
 
 clean:
 	rm -f $(LIB) $(PKG)/fa_main tests/fa_test tests/fa_tune tests/unit_kernels tests/micro/simd_mix tests/micro/valu_rates oracle/liboracle_attention.so

@@ -25,9 +25,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libflash_attention.so")
 
 FA_DTYPE_F32, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3, FA_DTYPE_F16 = 0, 1, 2, 3
+FA_FLAG_F16_WEIGHTS = 1     # flash_attention_ex: softmax weights rounded to fp16 instead of bf16 (bf16 inputs, d = 64 / 128)
 
 # every symbol include/flash_attention.h declares
-EXPORTS = ("flash_attention", "flash_attention_strided", "flash_attention_lse", "flash_attention_cross", "flash_attention_weights", "flash_attention_shard_range", "flash_attention_sharded",
+EXPORTS = ("flash_attention", "flash_attention_strided", "flash_attention_lse", "flash_attention_cross", "flash_attention_ex", "flash_attention_weights", "flash_attention_shard_range", "flash_attention_sharded",
            "flash_attention_plan",
            "flash_attention_error_string", "flash_attention_version")
 
@@ -69,6 +70,8 @@ def lib() -> ctypes.CDLL:
         L.flash_attention_lse.restype = i
         L.flash_attention_cross.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, f, b, i, i, sp, sp, sp, sp, vp]
         L.flash_attention_cross.restype = i
+        L.flash_attention_ex.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, f, b, i, i, sp, sp, sp, sp, ctypes.c_uint, vp]
+        L.flash_attention_ex.restype = i
         L.flash_attention_weights.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, b, i, sp, sp, vp]
         L.flash_attention_weights.restype = i
         ip, pp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p)
@@ -133,7 +136,7 @@ def plan(batchSize, numHeads, seqLen, dHead, is_causal=False, dtype=FA_DTYPE_BF1
     return {k: getattr(p, k) for k, _ in FaLaunchPlan._fields_}
 
 
-def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None, stream=None, return_lse=False):
+def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None, stream=None, return_lse=False, weights_dtype=None):
     """O = softmax(scale * Q K^T [+ causal mask]) V on [B, H, S, d] device tensors.
 
     Argument order and meaning follow the reference kernel (Q, K, V, O, batchSize, numHeads,
@@ -143,6 +146,8 @@ def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None
     API, kernels/FlashAttention.cuh:23); the causal mask stays ``k > q`` on absolute indices.
     Asynchronous on ``stream`` (default: torch's current stream).  Returns O, or ``(O, LSE)`` with
     ``return_lse=True`` (LSE: fp32 [B, H, S], natural-log sum of exp(scale * scores) over the visible keys).
+    ``weights_dtype=torch.float16`` (bf16 inputs, d = 64 or 128): the precision option FA_FLAG_F16_WEIGHTS of
+    flash_attention_ex -- softmax weights rounded to fp16 instead of bf16 before P.V.
     """
     import torch
     if not (Q.is_cuda and K.is_cuda and V.is_cuda):
@@ -163,8 +168,23 @@ def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None
     lse = torch.empty((B, H, S), dtype=torch.float32, device=Q.device) if return_lse else None
     common = (float(scale), bool(is_causal), _dtype_code(Q.dtype), _dtype_code(O.dtype))
     ptrs = (Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr())
+    flags = 0
+    if weights_dtype is not None:
+        if weights_dtype == torch.float16:
+            flags |= FA_FLAG_F16_WEIGHTS
+        elif weights_dtype != torch.bfloat16:
+            raise TypeError("weights_dtype must be torch.float16 or torch.bfloat16")
     with torch.cuda.device(Q.device):
-        if dense and Sk == S and lse is not None:
+        if flags:
+            st = []
+            for t in (Q, K, V, O):
+                if t.stride(3) != 1:
+                    raise ValueError("last dimension must be contiguous")
+                st.append(FaStrides(t.stride(0), t.stride(1), t.stride(2)))
+            refs = [ctypes.byref(x) for x in st]
+            rc = lib().flash_attention_ex(*ptrs, lse.data_ptr() if lse is not None else None, B, H, S, Sk, d, *common, *refs,
+                                          flags, _stream_ptr(stream))
+        elif dense and Sk == S and lse is not None:
             rc = lib().flash_attention_lse(*ptrs, lse.data_ptr(), B, H, S, d, *common, _stream_ptr(stream))
         elif dense and Sk == S:
             rc = lib().flash_attention(*ptrs, B, H, S, d, *common, _stream_ptr(stream))

@@ -13,8 +13,7 @@
 
 #include "../../include/flash_attention.h"
 #include "../helpers.hpp"
-#include "kernel_bf16.hip.h"
-#include "kernel_f32.hip.h"
+#include "launchers.hip.h"
 #include "generic.hip.h"
 #include "weights.hip.h"
 
@@ -66,7 +65,8 @@ static int validate(const void* Q, const void* K, const void* V, void* O, int B,
     if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP8_E4M3) return FA_ERR_UNSUPPORTED_DTYPE;
     if (o_dtype != FA_DTYPE_F32 && o_dtype != FA_DTYPE_BF16 && o_dtype != FA_DTYPE_F16) return FA_ERR_UNSUPPORTED_DTYPE;
     if (d > 256) return FA_ERR_UNSUPPORTED_DHEAD;
-    if (dtype == FA_DTYPE_FP8_E4M3 && (d > 128 || !(scale > 0.f))) return FA_ERR_UNSUPPORTED_DHEAD;   // fp8: MFMA path only
+    if (dtype == FA_DTYPE_FP8_E4M3 && d > 128) return FA_ERR_UNSUPPORTED_DHEAD;   // fp8: MFMA path only ...
+    if (dtype == FA_DTYPE_FP8_E4M3 && !(scale > 0.f)) return FA_ERR_BAD_SCALE;    // ... which folds a positive scale into exp2
     if ((d * elem_size(dtype)) % 16 != 0 || (d * elem_size(o_dtype)) % 16 != 0) return FA_ERR_UNSUPPORTED_DHEAD;
     return FA_OK;
 }
@@ -99,7 +99,7 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
         plan->q_block_rows = calculateSizeBlockQ(d, dtype);
         plan->kv_block_rows = calculateSizeBlockKV(d, dtype);
         plan->threads = 256;
-        plan->lds_bytes = d > 64 ? F32Cfg<128, false, float>::LDS_BYTES : F32Cfg<64, false, float>::LDS_BYTES;
+        plan->lds_bytes = f32_lds_bytes(d > 64 ? 128 : 64);
         const int nQ = getNumCta(S, plan->q_block_rows);
         const int64_t units = (int64_t)B * H * nQ;
         plan->grid = (int)(8 * ((units + 7) / 8));
@@ -130,61 +130,6 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
     return FA_OK;
 }
 
-// The MFMA kernels need up to 96 KiB of dynamic LDS: above the 64 KiB default, so the limit is raised once
-// per (kernel instantiation, device) -- function attributes are per device, and the multi-GPU driver calls
-// in from one host thread per device.  Not a stream operation; a repeated set is harmless.
-template <typename Kernel>
-static hipError_t raise_lds_limit(Kernel kernel, int bytes, std::atomic<bool> (&done)[64]) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
-    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
-    return e;
-}
-
-template <class Cfg>
-static hipError_t launch_mfma(const Params& p, const fa_launch_plan& plan, hipStream_t st) {
-    static std::atomic<bool> done[64];
-    const hipError_t attr = raise_lds_limit(fwd_mfma_kernel<Cfg>, Cfg::LDS_BYTES, done);
-    if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((fwd_mfma_kernel<Cfg>), dim3(plan.grid), dim3(plan.threads), Cfg::LDS_BYTES, st, p);
-    return hipGetLastError();
-}
-
-template <int D, bool CAUSAL, int ESZ, bool PAD, bool LSE>
-static hipError_t launch_mfma_out2(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
-    if (o_dtype == FA_DTYPE_F32) return launch_mfma<ProdCfg<D, CAUSAL, float, ESZ, false, PAD, LSE>>(p, plan, st);
-    if (o_dtype == FA_DTYPE_BF16) return launch_mfma<ProdCfg<D, CAUSAL, __bf16, ESZ, false, PAD, LSE>>(p, plan, st);
-    return launch_mfma<ProdCfg<D, CAUSAL, _Float16, ESZ, false, PAD, LSE>>(p, plan, st);
-}
-// bf16 inputs: a call that also wants the LSE runs the instantiation that sums the unrounded weights (computers16.hip.h);
-// the fp8 kernels (32x32x16 engine) sum unrounded weights anyway
-template <int D, bool CAUSAL, int ESZ, bool PAD = false>
-static hipError_t launch_mfma_out(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
-    if constexpr (ESZ == 2) {
-        if (p.lse) return launch_mfma_out2<D, CAUSAL, ESZ, PAD, true>(p, plan, o_dtype, st);
-    }
-    return launch_mfma_out2<D, CAUSAL, ESZ, PAD, false>(p, plan, o_dtype, st);
-}
-
-template <class Cfg>
-static hipError_t launch_f32(const Params& p, const fa_launch_plan& plan, hipStream_t st) {
-    static std::atomic<bool> done[64];
-    const hipError_t attr = raise_lds_limit(fwd_f32_mfma_kernel<Cfg>, Cfg::LDS_BYTES, done);
-    if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((fwd_f32_mfma_kernel<Cfg>), dim3(plan.grid), dim3(plan.threads), Cfg::LDS_BYTES, st, p);
-    return hipGetLastError();
-}
-
-template <int D, bool CAUSAL, bool PAD = false>
-static hipError_t launch_f32_out(const Params& p, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
-    if (o_dtype == FA_DTYPE_F32) return launch_f32<F32Cfg<D, CAUSAL, float, PAD>>(p, plan, st);
-    if (o_dtype == FA_DTYPE_BF16) return launch_f32<F32Cfg<D, CAUSAL, __bf16, PAD>>(p, plan, st);
-    return launch_f32<F32Cfg<D, CAUSAL, _Float16, PAD>>(p, plan, st);
-}
-
 template <typename InT, typename OutT>
 static hipError_t launch_generic_io(const Params& p, const fa_launch_plan& plan, int d, bool causal, hipStream_t st) {
     dim3 grid(plan.grid), block(plan.threads);
@@ -211,9 +156,12 @@ static hipError_t launch_generic(const Params& p, const fa_launch_plan& plan, in
 
 static int run(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int S, int Sk, int d,
                float scale, bool causal, int dtype, int o_dtype, const fa_strides* sQ,
-               const fa_strides* sK, const fa_strides* sV, const fa_strides* sO, void* stream) {
+               const fa_strides* sK, const fa_strides* sV, const fa_strides* sO, void* stream, unsigned flags = 0) {
     int rc = validate(Q, K, V, O, B, H, S, d, scale, dtype, o_dtype);
     if (rc != FA_OK) return rc;
+    if (flags & ~(unsigned)FA_FLAG_F16_WEIGHTS) return FA_ERR_BAD_FLAGS;
+    // the fp16-weights option exists for bf16 inputs at the natively instantiated head dimensions
+    if ((flags & FA_FLAG_F16_WEIGHTS) && !(dtype == FA_DTYPE_BF16 && (d == 64 || d == 128) && scale > 0.f)) return FA_ERR_BAD_FLAGS;
     if (Sk <= 0 || Sk > (1 << 24)) return FA_ERR_BAD_SHAPE;
     if (lse && !aligned16(lse)) return FA_ERR_MISALIGNED;
     const int esz = elem_size(dtype), osz = elem_size(o_dtype);
@@ -237,19 +185,14 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
     p.dbg = nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
-    if (plan.kernel_id == 3) {
-        if (d == 128)     e = causal ? launch_f32_out<128, true>(p, plan, o_dtype, st) : launch_f32_out<128, false>(p, plan, o_dtype, st);
-        else if (d == 64) e = causal ? launch_f32_out<64, true>(p, plan, o_dtype, st) : launch_f32_out<64, false>(p, plan, o_dtype, st);
-        else if (d > 64)  e = causal ? launch_f32_out<128, true, true>(p, plan, o_dtype, st) : launch_f32_out<128, false, true>(p, plan, o_dtype, st);
-        else              e = causal ? launch_f32_out<64, true, true>(p, plan, o_dtype, st) : launch_f32_out<64, false, true>(p, plan, o_dtype, st);
-    } else if (plan.kernel_id == 2) {
-        if (d == 128) e = causal ? launch_mfma_out<128, true, 1>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 1>(p, plan, o_dtype, st);
-        else          e = causal ? launch_mfma_out<128, true, 1, true>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 1, true>(p, plan, o_dtype, st);
-    } else if (plan.kernel_id == 1) {
-        if (d == 128)     e = causal ? launch_mfma_out<128, true, 2>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 2>(p, plan, o_dtype, st);
-        else if (d == 64) e = causal ? launch_mfma_out<64, true, 2>(p, plan, o_dtype, st) : launch_mfma_out<64, false, 2>(p, plan, o_dtype, st);
-        else if (d > 64)  e = causal ? launch_mfma_out<128, true, 2, true>(p, plan, o_dtype, st) : launch_mfma_out<128, false, 2, true>(p, plan, o_dtype, st);
-        else              e = causal ? launch_mfma_out<64, true, 2, true>(p, plan, o_dtype, st) : launch_mfma_out<64, false, 2, true>(p, plan, o_dtype, st);
+    if (plan.kernel_id == 3) {          // fp32 inputs: exact-fp32 MFMA kernel at D = 128 / 64 (narrower rows zero-padded)
+        e = d > 64 ? launch_f32_d128(p, plan, causal, d != 128, o_dtype, st) : launch_f32_d64(p, plan, causal, d != 64, o_dtype, st);
+    } else if (plan.kernel_id == 2) {   // fp8 e4m3fn inputs
+        e = launch_fp8_d128(p, plan, causal, d != 128, o_dtype, st);
+    } else if (plan.kernel_id == 1 && (flags & FA_FLAG_F16_WEIGHTS)) {
+        e = launch_bf16_p16(p, plan, causal, d, o_dtype, st);
+    } else if (plan.kernel_id == 1) {   // bf16 inputs
+        e = d > 64 ? launch_bf16_d128(p, plan, causal, d != 128, o_dtype, st) : launch_bf16_d64(p, plan, causal, d != 64, o_dtype, st);
     } else if (dtype == FA_DTYPE_F32) {
         e = launch_generic<float>(p, plan, d, causal, o_dtype, st);
     } else {
@@ -289,6 +232,14 @@ int flash_attention_cross(const void* Q, const void* K, const void* V, void* O, 
                           void* stream) {
     return fa::run(Q, K, V, O, LSE, batchSize, numHeads, seqLenQ, seqLenK, dHead, scale, is_causal, dtype, o_dtype, sQ,
                    sK, sV, sO, stream);
+}
+
+int flash_attention_ex(const void* Q, const void* K, const void* V, void* O, float* LSE, int batchSize, int numHeads,
+                       int seqLenQ, int seqLenK, int dHead, float scale, bool is_causal, int dtype, int o_dtype,
+                       const fa_strides* sQ, const fa_strides* sK, const fa_strides* sV, const fa_strides* sO,
+                       unsigned flags, void* stream) {
+    return fa::run(Q, K, V, O, LSE, batchSize, numHeads, seqLenQ, seqLenK, dHead, scale, is_causal, dtype, o_dtype, sQ,
+                   sK, sV, sO, stream, flags);
 }
 
 int flash_attention_weights(const void* Q, const void* K, const float* LSE, float* P, int batchSize, int numHeads,
@@ -379,7 +330,8 @@ const char* flash_attention_error_string(int code) {
         case FA_ERR_BAD_SHAPE: return "batchSize/numHeads/seqLen/dHead out of range";
         case FA_ERR_UNSUPPORTED_DHEAD: return "unsupported dHead for this dtype";
         case FA_ERR_UNSUPPORTED_DTYPE: return "unsupported dtype / o_dtype";
-        case FA_ERR_BAD_SCALE: return "scale is not finite";
+        case FA_ERR_BAD_SCALE: return "scale is not finite (fp8 inputs: not positive)";
+        case FA_ERR_BAD_FLAGS: return "unknown flag, or a flag that does not apply to this dtype / dHead";
         case FA_ERR_BAD_STRIDE: return "bad or misaligned stride";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown flash_attention error";
     }

@@ -30,17 +30,12 @@
 //                 LSE (C::SUM_MFMA = false) keep the fp32 sum of the UNROUNDED weights by v_add_f32 instead: the
 //                 log-sum-exp is then exact to fp32 rounding (the bf16-rounded sum is off by up to 2^-9 relative).
 //
-// Schedule.  An iteration is [ P.V of tile t | QK^T of tile t+1 ] with the workgroup barrier in FRONT of the P.V phase:
-//   * the first V^T fragments of tile t are requested before that barrier (the tile has been visible for a whole iteration) and
-//     P(t) is already in registers, so the MFMAs restart the moment the barrier opens -- with the barrier in front of the QK^T
-//     phase every wave began an iteration by waiting for LDS reads of the tile the barrier had just published;
-//   * ONE score buffer (32 registers instead of 64 ping-pong): S(t+1)'s key groups 0, 1 are exponentiated in the second half of
-//     the QK^T phase that produces them (-> P(t+1), k-step 0, ready at the barrier), key groups 2, 3 in the first half of the
-//     following P.V phase (-> k-step 1, needed from its slot SB/2 on); the next QK^T phase then overwrites them in that order.
-// SA = 2*KG*KS + SB = 2*2*D/16 MFMAs per tile, one per slot, fenced by sched_barrier(0) (hipcc otherwise hoists the softmax in
-// front of the MFMAs).  The tracked pass (running max, lazy rescale) takes all exponentials of S(t+1) after its decision at the
-// end of the iteration: it is the rare fallback and runs serially.
+// Slots: SA = 2*KG*KS (QK^T of tile t+1) + SB = 2*2*D/16 (P.V of tile t) MFMAs per tile, one per slot, fenced by
+// sched_barrier(0).  Score element E (0..31) = (k-step kk = E/16, query group qg = (E/8)%2, j = E%8) goes to overall slot
+// E*SPAN/32 with SPAN = SA + SB/2, which meets "P fragment (kk, qg) complete before its first P.V slot".
 #pragma once
+
+#include <type_traits>
 
 #include "loaders.hip.h"
 
@@ -65,7 +60,9 @@ struct WaveCompute16 {
     static constexpr int NE = 32;                  // score elements per lane per tile
     static constexpr int SPAN = SA + SB / 2;       // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
-    using Stage = BufStage<D, ESZ, 8, C::PAD, true>;
+    using Stage = BufStage<D, ESZ, 8, C::PAD, true, C::P_F16>;
+    // the P.V operand type: bf16, or fp16 with the fp16-weights option (weights rounded to 11 bits instead of 8; V staged as fp16)
+    using pv_t = std::conditional_t<C::P_F16, f16x8, bf16x8>;
     using ScoresT = Scores16;
     static constexpr int NL = Stage::NL, NW = Stage::NW;
     static_assert(2 * NL <= SA && 2 * NW <= SB / 2 + 1, "staging does not fit the slot plan");
@@ -80,7 +77,8 @@ struct WaveCompute16 {
     u32x4 kf[NPRE];
     bf16x8 vf[VPRE + 1];
     uint32_t pw[QG][2][4];   // P(t) as packed bf16 pairs: [query group][k-step][word w = elements 2w, 2w+1]
-    float p_even, sum_a[QG], sum_b[QG];
+    float mx_a[QG], mx_b[QG], p_even, sum_a[QG], sum_b[QG];
+    bool need;
     unsigned long long t_mid = 0, t_end = 0;   // STAMP builds only
 
     __host__ __device__ static constexpr int elem_slot(int E) { return E * SPAN / NE; }
@@ -100,10 +98,12 @@ struct WaveCompute16 {
         if constexpr (C::SUM_MFMA) return lsum[qg][0];
         else return sum_all_quarters(l[qg]);
     }
-    __device__ __forceinline__ static bf16x8 ones_frag() {
-        u32x4 v = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-        return __builtin_bit_cast(bf16x8, v);
+    __device__ __forceinline__ static pv_t ones_frag() {
+        constexpr uint32_t one2 = C::P_F16 ? 0x3c003c00u : 0x3f803f80u;
+        u32x4 v = {one2, one2, one2, one2};
+        return __builtin_bit_cast(pv_t, v);
     }
+    __device__ __forceinline__ static uint32_t pack_p(float lo, float hi) { return C::P_F16 ? pack_f16(lo, hi) : pack_bf16(lo, hi); }
 
     // Q fragment (qg, ks) of row q = row0 + 16*qg + (lane&15): 16 bytes at byte 64*ks + 16*h4 of the row.
     __device__ __forceinline__ void load_q(const char* Qh, int64_t qS_bytes, int row0, int S, int lane, int row_bytes = D * ESZ) {
@@ -214,63 +214,55 @@ struct WaveCompute16 {
     }
 
     // ---- softmax slices ------------------------------------------------------------------------
-    // Element E (0..31) = (k-step kk = E/16, query group qg = (E/8)%2, j = E%8) -> score register s[2*kk + (j>>2)][qg][j&3],
-    // key kv0 + 16*kg + 4*h4 + reg.  MASKED: the key is visible iff 16*kg + reg <= limrel[qg] (mask_bounds).
-    __device__ __forceinline__ void mask_bounds(int (&limrel)[QG], int kv0, int q_row0, int S, int lane) const {
-#pragma unroll
-        for (int qg = 0; qg < QG; ++qg) {
-            const int qi = q_row0 + 16 * qg + (lane & 15);
-            const int lim = C::CAUSAL ? (qi < S - 1 ? qi : S - 1) : S - 1;
-            limrel[qg] = lim - kv0 - 4 * (lane >> 4);
-        }
-    }
-    template <int E, bool MASKED>
-    __device__ __forceinline__ void exp_elem(const Scores16& sc, float c, const int (&limrel)[QG]) {
+    template <int E>
+    __device__ __forceinline__ void exp_elem(const Scores16& cur, float c) {
         constexpr int kk = E / 16, qg = (E / 8) % 2, j = E % 8, kg = 2 * kk + (j >> 2), reg = j & 3;
-        float x = sc.s[kg][qg][reg];
-        if constexpr (MASKED) x = (16 * kg + reg) > limrel[qg] ? -INFINITY : x;
-        const float p = fast_exp2(fmaf(x, c, -m[qg]));
+        const float p = fast_exp2(fmaf(cur.s[kg][qg][reg], c, -m[qg]));
         if constexpr (!C::SUM_MFMA) {
             if constexpr (j & 1) sum_b[qg] += p;
             else sum_a[qg] += p;
         }
         if constexpr (j & 1) {
-            pw[qg][kk][j >> 1] = pack_bf16(p_even, p);
+            pw[qg][kk][j >> 1] = pack_p(p_even, p);
             if constexpr (!C::SUM_MFMA) asm volatile("" : "+v"(sum_a[qg]), "+v"(sum_b[qg]));   // keep the adds in this slot (hipcc sinks them)
         } else {
             p_even = p;
         }
     }
-    // exponentials of elements [E0, E1), compiler-scheduled (prologue; tracked pass)
-    template <int E0, int E1, bool MASKED>
-    __device__ __forceinline__ void exp_range(const Scores16& sc, float c, const int (&limrel)[QG]) {
-        if constexpr (E0 < E1) {
-            exp_elem<E0, MASKED>(sc, c, limrel);
-            exp_range<E0 + 1, E1, MASKED>(sc, c, limrel);
+    template <int SLOT, int E = 0>
+    __device__ __forceinline__ void exp_slot(const Scores16& cur, float c) {
+        if constexpr (E < NE) {
+            if constexpr (elem_slot(E) == SLOT) exp_elem<E>(cur, c);
+            exp_slot<SLOT, E + 1>(cur, c);
         }
     }
-    // Which slot carries element E.  P.V phase of tile t: the elements of k-step 1 (E >= 16) of S(t), in its first SB/2 slots
-    // (P fragment (kk = 1, .) is first needed at slot SB/2).  QK^T phase (S(t+1)): the elements of k-step 0 (E < 16) of the NEW
-    // tile, in its second half -- the accumulators of key groups 0, 1 are complete after the first SA/2 slots.
-    __host__ __device__ static constexpr int pv_elem_slot(int E) { return (E - 16) * SB / 32; }
-    __host__ __device__ static constexpr int qk_elem_slot(int E) { return SA / 2 + E * SA / 32; }
-    template <int J, bool MASKED, int E = 16>
-    __device__ __forceinline__ void exp_pv_slot(const Scores16& sc, float c, const int (&limrel)[QG]) {
-        if constexpr (E < 32) {
-            if constexpr (pv_elem_slot(E) == J) exp_elem<E, MASKED>(sc, c, limrel);
-            exp_pv_slot<J, MASKED, E + 1>(sc, c, limrel);
-        }
-    }
-    template <int I, bool MASKED, int E = 0>
-    __device__ __forceinline__ void exp_qk_slot(const Scores16& sc, float c, const int (&limrel)[QG]) {
-        if constexpr (E < 16) {
-            if constexpr (qk_elem_slot(E) == I) exp_elem<E, MASKED>(sc, c, limrel);
-            exp_qk_slot<I, MASKED, E + 1>(sc, c, limrel);
-        }
-    }
-    __device__ __forceinline__ bf16x8 p_frag(int qg, int kk) const {
+    __device__ __forceinline__ pv_t p_frag(int qg, int kk) const {
         u32x4 v = {pw[qg][kk][0], pw[qg][kk][1], pw[qg][kk][2], pw[qg][kk][3]};
-        return __builtin_bit_cast(bf16x8, v);
+        return __builtin_bit_cast(pv_t, v);
+    }
+    // tracked pass: v_max3 chains over 64/SB values of S(t+1) in slot J (J < SB/2); 32 values in all
+    template <int J>
+    __device__ __forceinline__ void max3_slot(const Scores16& n) {
+        constexpr int PER = 64 / SB;
+#pragma unroll
+        for (int k = 0; k < PER; k += 2) {
+            const int E = J * PER + k, qg = E / 16, e = E % 16;      // per query group: 16 values = [kg][reg]
+            const float x0 = n.s[e >> 2][qg][e & 3], x1 = n.s[(e + 1) >> 2][qg][(e + 1) & 3];
+            if ((k >> 1) & 1) mx_b[qg] = fmaxf(fmaxf(mx_b[qg], x0), x1);
+            else mx_a[qg] = fmaxf(fmaxf(mx_a[qg], x0), x1);
+        }
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) asm volatile("" : "+v"(mx_a[qg]), "+v"(mx_b[qg]));
+    }
+    __device__ __forceinline__ void decide(float c) {
+        bool any = false;
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+            const float mx = max_all_quarters(fmaxf(mx_a[qg], mx_b[qg])) * c;
+            any = any || (mx > m[qg] + (float)C::THR);
+            mx_a[qg] = mx;   // keep the scaled row max for the rescale body
+        }
+        need = __any(any);
     }
 
     // V^T A-fragment v = (k-step kk = v / DG, d group dg = v % DG): two transposed reads (16-key halves jj = 0, 1)
@@ -280,133 +272,96 @@ struct WaveCompute16 {
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
-    // the first VPRE V^T fragments of a tile: issued BEFORE the barrier that precedes the tile's P.V phase (the tile has been
-    // visible since the barrier before), so the first MFMAs after the barrier wait for nothing
-    __device__ __forceinline__ void v_prefetch(lds_ptr vimg, int vbase) {
-#pragma unroll
-        for (int v = 0; v < VPRE; ++v) vf[v] = v_frag(vimg, vbase, v / DG, v % DG);
-    }
-    static constexpr int PREFETCH_LGKM = 2 * VPRE;   // LDS operations a wave has in flight at that barrier (they complete in order)
 
     // ---- the slots -----------------------------------------------------------------------------
-    // Iteration t = [ P.V of tile t | QK^T of tile t+1 ], ONE score buffer:
-    //   P.V slot J:  V^T fragment v = J / QG (k-step v / DG, d group v % DG), query group J % QG;
-    //                exp of S(t), k-step 1, in slots < SB/2; buffer_load #n of tile t+2 at J = 1 + 2n; the last NPRE slots
-    //                request the first K fragments of the QK^T phase.
-    //   QK^T slot I: K fragment f = I / QG (key group f / KS, k-step f % KS), query group I % QG; a chain's first MFMA takes C = 0
-    //                (the old S(t) registers of key groups 0, 1 were consumed in the previous QK^T phase, those of key groups
-    //                2, 3 in the P.V phase just before); ds_write_b128 #n of tile t+2 at I = SA/2 - 2*NW + 2n;
-    //                exp of the NEW S(t+1), k-step 0, in slots >= SA/2.
-    template <bool EXPS, bool MASKED, int J>
-    __device__ __forceinline__ void slots_pv(Stage& st, int t_load, lds_ptr v_cur, lds_ptr k_next, int kbase, int vbase, float c,
-                                             const Scores16& sc, const int (&lim_cur)[QG]) {
+    // phase A slot I: K fragment f = I / QG, query group I % QG
+    template <int I>
+    __device__ __forceinline__ void slots_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase,
+                                            float c, const Scores16& cur, Scores16& nxt) {
+        if constexpr (I < SA) {
+            constexpr int f = I / QG, qg = I % QG;
+            if constexpr (C::VALU_FIRST) exp_slot<I>(cur, c);
+            qk_mfma<f, qg>(kf[f % NPRE], nxt);
+            if constexpr (qg == QG - 1 && f + NPRE < NF) kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
+            if constexpr (I >= SA - VPRE) {   // the last VPRE phase-A slots start the V^T window of phase B
+                constexpr int v = I - (SA - VPRE);
+                vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DG, v % DG);
+            }
+            if constexpr (!C::DBG_NOLOAD && (I & 1) && (I >> 1) < NL) st.template load<(I >> 1)>(t_load);
+            if constexpr (!C::VALU_FIRST) exp_slot<I>(cur, c);
+            __builtin_amdgcn_sched_barrier(0);
+            slots_a<I + 1>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        }
+    }
+    // phase B slot J: V^T fragment v = J / QG (k-step v / DG, d group v % DG), query group J % QG
+    template <bool TRACK, int J>
+    __device__ __forceinline__ void slots_b(Stage& st, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
+                                            const Scores16& cur, const Scores16& nxt) {
         if constexpr (J < SB) {
             constexpr int v = J / QG, qg = J % QG, kk = v / DG, dg = v % DG;
-            o[qg][dg] = mfma_16x16x32(vf[v % (VPRE + 1)], p_frag(qg, kk), o[qg][dg]);
+            o[qg][dg] = mfma_16x16x32(__builtin_bit_cast(pv_t, vf[v % (VPRE + 1)]), p_frag(qg, kk), o[qg][dg]);
             if constexpr (C::SUM_MFMA && dg == 1) lsum[qg] = mfma_16x16x32(ones_frag(), p_frag(qg, kk), lsum[qg]);   // row sums of this k-step
             if constexpr (qg == QG - 1 && v + VPRE < NV) {
                 constexpr int vn = v + VPRE;
                 vf[vn % (VPRE + 1)] = v_frag(v_cur, vbase, vn / DG, vn % DG);
             }
-            if constexpr (EXPS) exp_pv_slot<J, MASKED>(sc, c, lim_cur);
-            if constexpr (!C::DBG_NOLOAD && (J & 1) && (J >> 1) < NL) st.template load<(J >> 1)>(t_load);
-            if constexpr (J >= SB - NPRE) kf[J - (SB - NPRE)] = k_read(k_next, kbase, J - (SB - NPRE));
+            exp_slot<SA + J>(cur, c);
+            if constexpr (TRACK && J < SB / 2) max3_slot<J>(nxt);
+            if constexpr (TRACK && J == SB / 2) decide(c);
+            if constexpr (J >= SB / 2 && ((J - SB / 2) & 1) == 0 && (J - SB / 2) / 2 < NW)
+                st.template write<(J - SB / 2) / 2>(wr_slot);
             __builtin_amdgcn_sched_barrier(0);
-            slots_pv<EXPS, MASKED, J + 1>(st, t_load, v_cur, k_next, kbase, vbase, c, sc, lim_cur);
-        }
-    }
-    template <bool EXPS, bool MASKED, int I>
-    __device__ __forceinline__ void slots_qk(Stage& st, lds_ptr wr_slot, lds_ptr k_next, int kbase, float c, Scores16& sc,
-                                             const int (&lim_nxt)[QG]) {
-        if constexpr (I < SA) {
-            constexpr int f = I / QG, qg = I % QG, kg = f / KS, ks = f % KS;
-            constexpr int W0 = SA / 2 - 2 * NW;
-            static_assert(W0 >= 0, "staging writes do not fit the first half of the QK^T phase");
-            if constexpr (ks == 0)
-                sc.s[kg][qg] = mfma_16x16x32(__builtin_bit_cast(bf16x8, kf[f % NPRE]), __builtin_bit_cast(bf16x8, qf[qg][ks]), f32x4{0.f, 0.f, 0.f, 0.f});
-            else
-                sc.s[kg][qg] = mfma_16x16x32(__builtin_bit_cast(bf16x8, kf[f % NPRE]), __builtin_bit_cast(bf16x8, qf[qg][ks]), sc.s[kg][qg]);
-            if constexpr (qg == QG - 1 && f + NPRE < NF) kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
-            if constexpr (I >= W0 && I < SA / 2 && ((I - W0) & 1) == 0) st.template write<(I - W0) / 2>(wr_slot);
-            if constexpr (EXPS) exp_qk_slot<I, MASKED>(sc, c, lim_nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            slots_qk<EXPS, MASKED, I + 1>(st, wr_slot, k_next, kbase, c, sc, lim_nxt);
+            slots_b<TRACK, J + 1>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         }
     }
 
-    // Softmax of the FIRST tile of a pass, after qk_all / mask / first_max (S(0) complete and masked in place):
-    // optimistic pass: only k-step 0 (the rest rides in the P.V phase of iteration 0); tracked pass: all of it.
-    template <bool TRACK>
-    __device__ __forceinline__ void softmax_first(const Scores16& sc, float c) {
-        const int none[QG] = {0, 0};
+    // One tile: cur = S(t) (consumed), nxt = S(t+1) (produced).  Same contract as WaveCompute::tile_step.
+    template <bool TRACK, bool LAST = false>
+    __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
+                                              int kbase, int vbase, float c, const Scores16& cur, Scores16& nxt,
+                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane,
+                                              lds_ptr = nullptr) {
+        static_assert(!LAST, "the 16x16x32 path has no separate last-tile step");
 #pragma unroll
-        for (int qg = 0; qg < QG; ++qg) sum_a[qg] = sum_b[qg] = 0.f;
-        exp_range<0, TRACK ? 32 : 16, false>(sc, c, none);
+        for (int qg = 0; qg < QG; ++qg) {
+            mx_a[qg] = mx_b[qg] = -INFINITY;
+            sum_a[qg] = sum_b[qg] = 0.f;
+        }
+        zero(nxt);
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
+        __builtin_amdgcn_sched_barrier(0);
+        slots_a<0>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        if constexpr (C::STAMP) t_mid = cycle_stamp();
+        slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
+        if constexpr (C::STAMP) t_end = cycle_stamp();
         if constexpr (!C::SUM_MFMA) {
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg) l[qg] += sum_a[qg] + sum_b[qg];
         }
-    }
-
-    // One iteration.  sc: S(t) on entry (k-step 1 not yet exponentiated on the optimistic pass), S(t+1) on exit.
-    // has_next = false (the wave's last tile): the QK^T phase runs on whatever the ring holds and its exponentials are masked
-    // to zero (lim_nxt = -inf), so the MASKED instantiation must be used.  TRACK: running max with lazy rescale; every exponential
-    // of S(t+1) is taken after the decision, at the end of the iteration (the rare fallback pass: serial, always safe).
-    template <bool TRACK, bool MASKED>
-    __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur, lds_ptr v_next,
-                                              int kbase, int vbase, float c, Scores16& sc, bool has_next, int kv0_cur, int q_row0,
-                                              int S, int lane) {
-        int lim_cur[QG] = {0, 0}, lim_nxt[QG] = {0, 0};
-        if constexpr (MASKED) {
-            mask_bounds(lim_cur, kv0_cur, q_row0, S, lane);
-            mask_bounds(lim_nxt, kv0_cur + 64, q_row0, S, lane);
-            if (!has_next) { lim_nxt[0] = -(1 << 30); lim_nxt[1] = -(1 << 30); }
-        }
+        // ONE rescale site (two sites that both multiply O make hipcc copy all accumulator registers per tile)
+        if (has_next && mask_next) {
+            mask(nxt, kv0_next, q_row0, S, lane);
+            if constexpr (TRACK) {
 #pragma unroll
-        for (int qg = 0; qg < QG; ++qg) sum_a[qg] = sum_b[qg] = 0.f;
-        __builtin_amdgcn_sched_barrier(0);
-        slots_pv<!TRACK, MASKED, 0>(st, t_load, v_cur, k_next, kbase, vbase, c, sc, lim_cur);
-        if constexpr (C::STAMP) t_mid = cycle_stamp();
-        slots_qk<!TRACK, MASKED, 0>(st, wr_slot, k_next, kbase, c, sc, lim_nxt);
-        if constexpr (C::STAMP) t_end = cycle_stamp();
-        if constexpr (TRACK) {
-            if (has_next) {
-                if constexpr (MASKED) {
-#pragma unroll
-                    for (int qg = 0; qg < QG; ++qg)
-#pragma unroll
-                        for (int kg = 0; kg < KG; ++kg)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) sc.s[kg][qg][r] = (16 * kg + r) > lim_nxt[qg] ? -INFINITY : sc.s[kg][qg][r];
-                }
-                bool any = false;
-                float mx[QG];
-#pragma unroll
-                for (int qg = 0; qg < QG; ++qg) {
-                    mx[qg] = max_all_quarters(row_max(sc, qg)) * c;
-                    any = any || (mx[qg] > m[qg] + (float)C::THR);
-                }
-                if (__any(any)) {
-#pragma unroll
-                    for (int qg = 0; qg < QG; ++qg) {
-                        const float mn = fmaxf(m[qg], mx[qg]);
-                        const float alpha = fast_exp2(m[qg] - mn);
-                        m[qg] = mn;
-                        lsum[qg] *= alpha;
-                        l[qg] *= alpha;
-#pragma unroll
-                        for (int i = 0; i < DG; ++i) o[qg][i] *= alpha;
-                    }
-                }
-                const int none[QG] = {0, 0};
-                exp_range<0, 32, false>(sc, c, none);
+                for (int qg = 0; qg < QG; ++qg) { mx_a[qg] = row_max(nxt, qg); mx_b[qg] = mx_a[qg]; }
+                decide(c);
             }
         }
-        if constexpr (!C::SUM_MFMA) {
+        if constexpr (TRACK) {
+            if (has_next && need) {
 #pragma unroll
-            for (int qg = 0; qg < QG; ++qg) l[qg] += sum_a[qg] + sum_b[qg];
+                for (int qg = 0; qg < QG; ++qg) {
+                    const float mn = fmaxf(m[qg], mx_a[qg]);
+                    const float alpha = fast_exp2(m[qg] - mn);
+                    m[qg] = mn;
+                    lsum[qg] *= alpha;
+                    l[qg] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < DG; ++i) o[qg][i] *= alpha;
+                }
+            }
         }
-        if (has_next) v_prefetch(v_next, vbase);
     }
 
     // True iff a row sum or any O accumulator of this lane is inf / NaN (x*0 is NaN for both); four independent chains.

@@ -51,6 +51,8 @@ struct Opt {
                                  // a higher clock on that shape (power).  -1: on for bf16 inputs with r = 1
     int sum_mfma = -1;           // 16x16x32 engine: row sums from ONES.P^T MFMAs (sums the bf16-rounded weights) instead of one v_add_f32
                                  // per score.  -1: on (the library turns it off in the kernels that return the LSE)
+    bool p_f16 = false;          // 16x16x32 engine: weights rounded to fp16 (11 significant bits) instead of bf16 (8), V staged as fp16, P.V
+                                 // on v_mfma_f32_16x16x32_f16: the precision option behind FA_FLAG_F16_WEIGHTS (needs |V| <= 65504)
     // ---- rejected by measurement, kept as arms of the tuner (numbers: causal / non-causal headline shape) ----
     int wg = 1;                  // K / V^T fragments consumed per s_waitcnt (1: hipcc's one wait per MFMA; 2: -2 %, 4: 0 %)
     int ring = 3;                // LDS ring slots: 3 (tile t+2 staged in iteration t) or 4 (tile t+3: the next tile's first K
@@ -82,6 +84,7 @@ struct KernelCfg {
     static constexpr bool M16 = (O.m16 < 0 ? true : O.m16 != 0) && ESZ_ == 2 && O.r == 1 && !O.asm_mfma && O.ring == 3 && !O.skip_last_qk &&
                                 !O.pk && !O.dot2 && O.wg == 1;
     static constexpr bool SUM_MFMA = M16 && (O.sum_mfma < 0 ? true : O.sum_mfma != 0);
+    static constexpr bool P_F16 = M16 && O.p_f16;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
     static constexpr int NWAVES = 8 / O.r;           // waves per workgroup (256 query rows)
@@ -114,7 +117,7 @@ struct RowSink {
 // One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the
 // result has to be recomputed with max tracking (only ever true for TRACK = false).
 template <class C, bool TRACK>
-__device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& w, typename WaveCompute<C>::Stage& st, lds_ptr smem,
+__device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>& w, typename WaveComputeOf<C>::Stage& st, lds_ptr smem,
                                                int n_tiles, int my_tiles, int q_row0, int lane,
                                                unsigned long long (&acc)[12], bool tile0_in_flight, RowSink& sink) {
     using G = TileGeom<C::D, C::ESZ>;
@@ -124,9 +127,9 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
     unsigned long long tp0 = 0, tp1 = 0, tp2 = 0;
     if constexpr (C::STAMP) tp0 = cycle_stamp();
     w.init();
-    using WC = WaveCompute<C>;
-    const int kbase = k_read_base(lane);
-    const int vbase = v_read_base(lane);
+    using WC = WaveComputeOf<C>;
+    const int kbase = C::M16 ? k16_read_base(lane) : k_read_base(lane);
+    const int vbase = C::M16 ? v16_read_base<C::D>(lane) : v_read_base(lane);
     const float c = p.scale_log2;
     auto needs_mask = [&](int t) { return (CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > S); };
     typename WC::ScoresT sA, sB;
@@ -225,97 +228,6 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveCompute<C>& 
             if (t + 1 < n_tiles) step(t + 1, kind_of(t + 1), sB, sA);
         }
     }
-    if constexpr (TRACK) return false;
-    else {
-        unsigned long long tc0 = 0;
-        if constexpr (C::STAMP) tc0 = cycle_stamp();
-        const bool bad = __syncthreads_or(my_tiles > 0 && w.not_finite()) != 0;
-        if constexpr (C::STAMP) acc[10] += cycle_stamp() - tc0;
-        return bad;
-    }
-}
-
-// The same pass on the 16x16x32 engine (computers16.hip.h): iteration t = [ P.V of tile t | QK^T of tile t+1 ], one score buffer,
-// the barrier in front of the P.V phase with the tile's first V^T fragments already requested.  Ring use is unchanged:
-// iteration t reads V(t) (slot t%3) and K(t+1) (slot (t+1)%3), requests the first V^T fragments of tile t+1, and stages tile
-// t+2 into slot (t+2)%3 = the slot of tile t-1, whose last reads every wave finished before the previous barrier.
-template <class C, bool TRACK>
-__device__ __forceinline__ bool attention_pass16(const Params& p, WaveCompute16<C>& w, typename WaveCompute16<C>::Stage& st, lds_ptr smem,
-                                                 int n_tiles, int my_tiles, int q_row0, int lane, unsigned long long (&acc)[12],
-                                                 bool tile0_in_flight) {
-    using G = TileGeom<C::D, C::ESZ>;
-    using WC = WaveCompute16<C>;
-    constexpr bool CAUSAL = C::CAUSAL;
-    constexpr int KVBLK = 64, SLOT = G::SLOT, KT = G::K_TILE;
-    const int S = p.Sk;   // key bound of the masks
-    unsigned long long tp0 = 0, tp1 = 0, tp2 = 0;
-    if constexpr (C::STAMP) tp0 = cycle_stamp();
-    w.init();
-    const int kbase = k16_read_base(lane), vbase = v16_read_base<C::D>(lane);
-    const float c = p.scale_log2;
-    auto needs_mask = [&](int t) { return (CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > S); };
-    Scores16 sc;
-
-    // Prologue: tile 0 (requested by the caller together with Q on the first pass) -> LDS, barrier; tile 1 is fetched while
-    // S(0) = K(0).Q^T, its row max and the first exponentials are computed; the first V^T fragments of tile 0 are requested.
-    if (!tile0_in_flight) st.load_all(0);
-    st.write_all(smem);
-    __syncthreads();
-    st.load_all(1);          // past-the-end tiles read as zeros (buffer range check)
-    if constexpr (C::STAMP) tp1 = cycle_stamp();
-    if (my_tiles > 0) {
-        w.qk_all(smem, kbase, sc);
-        if (needs_mask(0)) w.mask(sc, 0, q_row0, S, lane);
-        w.first_max(sc, c);   // m = row max of tile 0 (the reference of the optimistic pass)
-        w.template softmax_first<TRACK>(sc, c);
-    }
-    st.write_all(smem + SLOT);
-    if (my_tiles > 0) w.v_prefetch(smem + KT, vbase);
-    if (my_tiles > 0) asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(WC::PREFETCH_LGKM) : "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if constexpr (C::STAMP) { tp2 = cycle_stamp(); acc[8] += tp1 - tp0; acc[9] += tp2 - tp1; }
-
-    int so_cur = 0, so_nxt = SLOT, so_wr = 2 * SLOT;   // ring slot byte offsets of tiles t, t+1, t+2
-    // KIND 0: plain tile step; 1: the masked instantiation (diagonal / ragged tiles, and the wave's last tile, whose QK^T phase
-    // has no tile to score); 2: past this wave's causal diagonal -- it still stages its share of the tiles the others need.
-    // Three consecutive loops, ONE call site of each instantiation: alternatives inside one loop make hipcc merge the two
-    // versions of the 64 O accumulators with register copies (136 v_mov per tile) and spill.
-    auto iteration = [&](int t, auto kind_c) {
-        constexpr int KIND = decltype(kind_c)::value;
-        unsigned long long t0 = 0, t4 = 0, t6 = 0;
-        if constexpr (C::STAMP) t0 = cycle_stamp();
-        const bool has_next = KIND == 0 || (KIND == 1 && t + 1 < my_tiles);
-        if constexpr (KIND != 2) {
-            w.template tile_step<TRACK, KIND == 1>(st, t + 2, smem + so_wr, smem + so_nxt, smem + so_cur + KT, smem + so_nxt + KT, kbase,
-                                                   vbase, c, sc, has_next, t * KVBLK, q_row0, S, lane);
-        } else {
-            st.load_all(t + 2);
-            st.write_all(smem + so_wr);
-        }
-        if constexpr (C::STAMP) t4 = cycle_stamp();
-        if constexpr (!C::DBG_NOBAR) {
-            // not __syncthreads(): it would drain the V^T fragments just requested.  LDS operations of a wave complete in
-            // order and those reads are the last ones it issued, so this wait covers every ds_write of the staged tile.
-            if (has_next) asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(WC::PREFETCH_LGKM) : "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-        if constexpr (C::STAMP) {
-            t6 = cycle_stamp();
-            if constexpr (KIND != 2) { acc[1] += w.t_mid - t0; acc[2] += w.t_end - w.t_mid; acc[3] += t4 - w.t_end; acc[6] += 1; }
-            acc[5] += t6 - t4;
-        }
-        const int tmp = so_cur;
-        so_cur = so_nxt;
-        so_nxt = so_wr;
-        so_wr = tmp;
-    };
-    // every condition of the masked instantiation is monotone in t, so the plain steps form a prefix
-    int n_plain = 0;
-    while (n_plain + 1 < my_tiles && !needs_mask(n_plain + 1)) ++n_plain;
-    int t = 0;
-    for (; t < n_plain; ++t) iteration(t, std::integral_constant<int, 0>{});
-    for (; t < my_tiles; ++t) iteration(t, std::integral_constant<int, 1>{});
-    for (; t < n_tiles; ++t) iteration(t, std::integral_constant<int, 2>{});
     if constexpr (TRACK) return false;
     else {
         unsigned long long tc0 = 0;
@@ -426,14 +338,7 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
         // An opaque copy of the lane id keeps them inside the pass.
         int lane_p = lane;
         if constexpr (C::PERSIST) asm volatile("" : "+v"(lane_p));
-        if constexpr (C::M16) {
-            if constexpr (C::OPTIMISTIC) {
-                if (attention_pass16<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true))
-                    attention_pass16<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false);
-            } else {
-                attention_pass16<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true);
-            }
-        } else if constexpr (C::OPTIMISTIC) {
+        if constexpr (C::OPTIMISTIC) {
             if (attention_pass<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true, sink)) {
                 sink.stored = false;   // whatever was written early came from an overflowed pass
                 attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false, sink);

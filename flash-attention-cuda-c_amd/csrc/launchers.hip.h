@@ -1,0 +1,43 @@
+// launchers.hip.h -- how the host side starts a kernel instantiation, and the per-group entry points that the translation units
+// inst_*.hip define.  The kernels are spread over several translation units only so that they compile in parallel (one hipcc
+// process per group); FlashAttention.hip holds the C ABI, validation and geometry and calls the group entry points below.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+
+#include "../../include/flash_attention.h"
+#include "loaders.hip.h"
+
+namespace fa {
+
+// The MFMA kernels need up to 96 KiB of dynamic LDS: above the 64 KiB default, so the limit is raised once per
+// (kernel instantiation, device) -- function attributes are per device, and the multi-GPU driver calls in from one host
+// thread per device.  Not a stream operation; a repeated set is harmless.
+template <typename Kernel>
+static hipError_t raise_lds_limit(Kernel kernel, int bytes, std::atomic<bool> (&done)[64]) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
+    return e;
+}
+
+// ---- group entry points (each defined in exactly one inst_*.hip) ----
+// bf16 inputs, MFMA kernel instantiated at D = 128 / 64; pad: the tensors' head dimension is smaller than D;
+// lse: the instantiation that keeps the fp32 sum of the unrounded weights (computers16.hip.h)
+hipError_t launch_bf16_d128(const Params& p, const fa_launch_plan& plan, bool causal, bool pad, int o_dtype, hipStream_t st);
+hipError_t launch_bf16_d64(const Params& p, const fa_launch_plan& plan, bool causal, bool pad, int o_dtype, hipStream_t st);
+// bf16 inputs, fp16-weights precision option (d = 128 or 64 exactly)
+hipError_t launch_bf16_p16(const Params& p, const fa_launch_plan& plan, bool causal, int d, int o_dtype, hipStream_t st);
+// fp8 e4m3fn inputs (always the D = 128 instantiation)
+hipError_t launch_fp8_d128(const Params& p, const fa_launch_plan& plan, bool causal, bool pad, int o_dtype, hipStream_t st);
+// fp32 inputs, exact-fp32 MFMA kernel
+hipError_t launch_f32_d128(const Params& p, const fa_launch_plan& plan, bool causal, bool pad, int o_dtype, hipStream_t st);
+hipError_t launch_f32_d64(const Params& p, const fa_launch_plan& plan, bool causal, bool pad, int o_dtype, hipStream_t st);
+int f32_lds_bytes(int d_padded);
+
+}  // namespace fa

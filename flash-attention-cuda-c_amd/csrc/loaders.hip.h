@@ -112,7 +112,8 @@ __device__ __forceinline__ int v16_read_base(int lane) {
 // V16: the V image of the 16x16x32 kernels (TileGeom::v16_lds_off); its lanes are
 //   V lanes: key 8g + 4*((l>>3)&1) + ((l&7)>>1), 16-byte chunk 2*(l>>4) + (l&1)  [+8 for the second 128-byte half]
 // (each 8-lane group still writes 128 contiguous LDS bytes; +8 keys and +8 chunks cost the same strides as above).
-template <int D, int ESZ, int NWAVES = 8, bool PAD = false, bool V16 = false>
+// VF16: bf16 V is converted to fp16 on its way into the V image (the fp16-weights option of the 16x16x32 engine).
+template <int D, int ESZ, int NWAVES = 8, bool PAD = false, bool V16 = false, bool VF16 = false>
 struct BufStage {
     using G = TileGeom<D, ESZ>;
     static constexpr int HALVES = G::ROWB / 128;                 // 128-byte halves of a row
@@ -185,7 +186,8 @@ struct BufStage {
             lds_write_b128(slot_base, klds + gi * 128 + hf * 8192, PAD ? keep_if(kok[hf], r[N]) : r[N]);
         } else if constexpr (ESZ == 2) {
             constexpr int n = N - LOADS, gi = n / HALVES, hf = n % HALVES;
-            lds_write_b128(slot_base + G::K_TILE, vlds + gi * (G::DB * 512) + hf * 1024, PAD ? keep_if(vok[hf], r[N]) : r[N]);
+            const u32x4 v = PAD ? keep_if(vok[hf], r[N]) : r[N];
+            lds_write_b128(slot_base + G::K_TILE, vlds + gi * (G::DB * 512) + hf * 1024, VF16 ? bf16x8_to_f16x8(v) : v);
         } else {
             // fp8 V (ROWB = 128, one half): 16 e4m3fn bytes -> 16 bf16 (exact), two adjacent 16-byte chunks
             constexpr int n = (N - LOADS) / 2, W = (N - LOADS) % 2;   // load n of this tensor, low / high 8 bytes

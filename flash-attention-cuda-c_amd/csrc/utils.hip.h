@@ -41,6 +41,9 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
 __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma_16x16x32(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 // TIMING EXPERIMENT ONLY (Opt::dbg bit 3): two 16x16x32 MFMAs on the operands of one 32x32x16 -- same FLOPs, same
 // operand registers, half the accumulator registers written.  The numbers that come out mean nothing.
 __device__ __forceinline__ f32x16 mfma_as_two_16x16x32(bf16x8 a, bf16x8 b, f32x16 c, int which) {
@@ -171,6 +174,16 @@ __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
     v[0] = (_Float16)lo;
     v[1] = (_Float16)hi;
     return __builtin_bit_cast(uint32_t, v);
+}
+
+// 8 bf16 -> 8 fp16 (the fp16-weights option: V is staged as fp16).  Exact for every bf16 value whose magnitude lies in fp16's
+// normal range [2^-14, 65504] (8 significant bits fit 11); smaller magnitudes round to fp16 subnormals / zero (absolute error
+// < 2^-25), larger ones become inf -- v_cvt_pk_f16_f32 rounds to nearest even and does not saturate.
+__device__ __forceinline__ u32x4 bf16x8_to_f16x8(u32x4 v) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = pack_f16(bf16_lo(v[i]), bf16_hi(v[i]));
+    return r;
 }
 
 // 8 fp8 e4m3fn bytes (two dwords) -> 8 bf16, exactly (e4m3fn has 3 mantissa bits): 4 v_cvt_pk_f32_fp8 +

@@ -76,6 +76,8 @@ static std::vector<Variant> make_variants() {
     using T = __bf16;
     std::vector<Variant> v;
     v.push_back({"production (16x16x32 MFMAs)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
+    v.push_back({"fp16 weights (FA_FLAG_F16_WEIGHTS)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>});
+    v.push_back({"exact row sums (the LSE instantiation)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.sum_mfma = 0}>>});
     v.push_back({"32x32x16 MFMAs (round-1 production)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0}>>});
 #ifdef FA_TUNE_FULL   // the round-1 arms (rejected by measurement): ~3 more minutes of compile time
     v.push_back({"waits grouped by 2 (npre4 vpre3)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .wg = 2}>>});

@@ -45,7 +45,7 @@ def test_argument_validation_happens_before_any_launch():
     assert call(S=0) == -3 and call(B=-1) == -3                      # FA_ERR_BAD_SHAPE
     assert call(d=512) == -4 and call(d=3) == -4                     # FA_ERR_UNSUPPORTED_DHEAD
     assert call(dtype=2, d=144) == -4 and call(dtype=2, d=24) == -4  # fp8 e4m3fn: d <= 128, 16-byte rows
-    assert call(dtype=2, d=64, scale=-1.0) == -4                     # fp8: MFMA path only (scale > 0)
+    assert call(dtype=2, d=64, scale=-1.0) == -6                     # fp8: MFMA path only, which needs scale > 0 -> FA_ERR_BAD_SCALE
     assert call(dtype=9) == -5 and call(o=2) == -5                   # FA_ERR_UNSUPPORTED_DTYPE
     assert call(scale=float("nan")) == -6 and call(scale=float("inf")) == -6
     for code in range(-7, 1):
