@@ -222,9 +222,11 @@ struct WaveCompute16 {
             if constexpr (j & 1) sum_b[qg] += p;
             else sum_a[qg] += p;
         }
+        // (empty asm: pins the value in this slot -- hipcc otherwise sinks the arithmetic towards its first use, behind the MFMAs
+        //  or, when the slot sequence holds a branch, into the block behind it)
         if constexpr (j & 1) {
             pw[qg][kk][j >> 1] = pack_p(p_even, p);
-            if constexpr (!C::SUM_MFMA) asm volatile("" : "+v"(sum_a[qg]), "+v"(sum_b[qg]));   // keep the adds in this slot (hipcc sinks them)
+            if constexpr (!C::SUM_MFMA) asm volatile("" : "+v"(sum_a[qg]), "+v"(sum_b[qg]));
         } else {
             p_even = p;
         }
@@ -315,12 +317,15 @@ struct WaveCompute16 {
         }
     }
 
+    struct NoHook { __device__ __forceinline__ void operator()() const {} };
     // One tile: cur = S(t) (consumed), nxt = S(t+1) (produced).  Same contract as WaveCompute::tile_step.
-    template <bool TRACK, bool LAST = false>
+    // between(): called between the two phases (unit streaming: the next unit's Q fragments are requested there, when this
+    // unit's Q is dead -- the loads land under the P.V phase).
+    template <bool TRACK, bool LAST = false, class Between = NoHook>
     __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
                                               int kbase, int vbase, float c, const Scores16& cur, Scores16& nxt,
                                               bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane,
-                                              lds_ptr = nullptr) {
+                                              lds_ptr = nullptr, Between&& between = Between{}) {
         static_assert(!LAST, "the 16x16x32 path has no separate last-tile step");
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
@@ -330,9 +335,11 @@ struct WaveCompute16 {
         zero(nxt);
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
+        if constexpr (C::STREAM) t_load = st.select(t_load);   // the stream element's own unit and tile index
         __builtin_amdgcn_sched_barrier(0);
         slots_a<0>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_mid = cycle_stamp();
+        between();
         slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
         if constexpr (!C::SUM_MFMA) {
@@ -418,17 +425,20 @@ struct WaveCompute16 {
             }
         }
     }
-    // 2-byte outputs through this wave's private LDS region: row-major [32 rows][D], 16-byte chunk c of row q at chunk
-    // c ^ (q & mask); whole rows back out with 16-byte stores.  The caller guarantees the K/V ring is dead.
+    // 2-byte outputs through this wave's private LDS region, one query group (16 rows) at a time: row-major [16 rows][D], 16-byte
+    // chunk c of row q at chunk c ^ (q & mask); whole rows back out with 16-byte stores.  region: 16*D*2 bytes, not aliased by
+    // anything live.  (The LDS executes a wave's accesses in order, so the second group's writes cannot overtake the first
+    // group's reads.)
     template <typename OutT>
     __device__ __forceinline__ void store_o_lds(lds_ptr region, char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S,
                                                 int lane, int orow_bytes = D * 2) {
         static_assert(sizeof(OutT) == 2, "LDS epilogue is for bf16 / f16 outputs");
         constexpr int ROWB = D * 2, CHUNKS = ROWB / 16;
-        const int h4 = lane >> 4;
+        constexpr int ROWS_PER_INST = 64 / CHUNKS;                          // 4 (D=128) or 8 (D=64)
+        const int h4 = lane >> 4, q = lane & 15;
+        const int rr = lane / CHUNKS, cc = lane % CHUNKS;
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
-            const int q = 16 * qg + (lane & 15);
             const float l_tot = row_sum_total(qg);
             store_lse(lse_head, l_tot, qg, row0, S, lane);
             const float inv = 1.0f / l_tot;
@@ -441,50 +451,45 @@ struct WaveCompute16 {
                 const int chunk = 2 * dg + (h4 >> 1), half8 = (h4 & 1) * 8;          // d0 = 16*dg + 4*h4 -> byte 2*d0
                 *reinterpret_cast<FA_LDS u32x2*>(region + q * ROWB + (((chunk ^ q) & (CHUNKS - 1)) << 4) + half8) = v;
             }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): only this wave's own ds_writes have to land
-        constexpr int ROWS_PER_INST = 64 / CHUNKS;                          // 4 (D=128) or 8 (D=64)
-        const int rr = lane / CHUNKS, cc = lane % CHUNKS;
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): only this wave's own ds_writes have to land
 #pragma unroll
-        for (int i = 0; i < 32 / ROWS_PER_INST; ++i) {
-            const int row = i * ROWS_PER_INST + rr;
-            const u32x4 v = *reinterpret_cast<FA_LDS const u32x4*>(region + row * ROWB + (((cc ^ row) & (CHUNKS - 1)) << 4));
-            if (row0 + row < S && (!C::PAD || cc * 16 < orow_bytes))
-                *reinterpret_cast<u32x4*>(Oh + (int64_t)(row0 + row) * oS_bytes + cc * 16) = v;
+            for (int i = 0; i < 16 / ROWS_PER_INST; ++i) {
+                const int row = i * ROWS_PER_INST + rr, grow = row0 + 16 * qg + row;
+                const u32x4 v = *reinterpret_cast<FA_LDS const u32x4*>(region + row * ROWB + (((cc ^ row) & (CHUNKS - 1)) << 4));
+                if (grow < S && (!C::PAD || cc * 16 < orow_bytes))
+                    *reinterpret_cast<u32x4*>(Oh + (int64_t)grow * oS_bytes + cc * 16) = v;
+            }
         }
     }
-    // 4-byte outputs through LDS, 64 columns at a time ([32 rows][64 floats] half tiles; see WaveCompute::store_o_lds32).
+    // 4-byte outputs through LDS, one query group and 64 columns at a time ([16 rows][64 floats] pieces, 16-byte chunk c of row
+    // q at chunk c ^ q); 256 contiguous bytes of a row per 16 lanes back out.  region: 16*256 bytes.
     template <typename OutT>
     __device__ __forceinline__ void store_o_lds32(lds_ptr region, char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S,
                                                   int lane, int orow_bytes = D * 4) {
         static_assert(sizeof(OutT) == 4, "for fp32 outputs");
-        const int h4 = lane >> 4;
-        float inv[QG];
+        const int h4 = lane >> 4, q = lane & 15;
+        const int rr = lane >> 4, cc = lane & 15;
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
             const float l_tot = row_sum_total(qg);
             store_lse(lse_head, l_tot, qg, row0, S, lane);
-            inv[qg] = 1.0f / l_tot;
-        }
-        const int rr = lane >> 4, cc = lane & 15;
+            const float inv = 1.0f / l_tot;
 #pragma unroll
-        for (int hf = 0; hf < D / 64; ++hf) {
-            if (hf > 0) __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's reads of the previous half are done
-#pragma unroll
-            for (int qg = 0; qg < QG; ++qg)
+            for (int hf = 0; hf < D / 64; ++hf) {
 #pragma unroll
                 for (int dd = 0; dd < 4; ++dd) {
-                    const int dg = 4 * hf + dd, cidx = 4 * dd + h4, q = 16 * qg + (lane & 15);
-                    const f32x4 v = {o[qg][dg][0] * inv[qg], o[qg][dg][1] * inv[qg], o[qg][dg][2] * inv[qg], o[qg][dg][3] * inv[qg]};
+                    const int dg = 4 * hf + dd, cidx = 4 * dd + h4;
+                    const f32x4 v = {o[qg][dg][0] * inv, o[qg][dg][1] * inv, o[qg][dg][2] * inv, o[qg][dg][3] * inv};
                     *reinterpret_cast<FA_LDS f32x4*>(region + q * 256 + (((cidx ^ q) & 15) << 4)) = v;
                 }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = 4 * i + rr;
-                const f32x4 v = *reinterpret_cast<FA_LDS const f32x4*>(region + row * 256 + (((cc ^ row) & 15) << 4));
-                if (row0 + row < S && (!C::PAD || hf * 256 + cc * 16 < orow_bytes))
-                    *reinterpret_cast<f32x4*>(Oh + (int64_t)(row0 + row) * oS_bytes + hf * 256 + cc * 16) = v;
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 4 * i + rr, grow = row0 + 16 * qg + row;
+                    const f32x4 v = *reinterpret_cast<FA_LDS const f32x4*>(region + row * 256 + (((cc ^ row) & 15) << 4));
+                    if (grow < S && (!C::PAD || hf * 256 + cc * 16 < orow_bytes))
+                        *reinterpret_cast<f32x4*>(Oh + (int64_t)grow * oS_bytes + hf * 256 + cc * 16) = v;
+                }
             }
         }
     }

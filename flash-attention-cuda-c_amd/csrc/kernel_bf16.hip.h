@@ -40,7 +40,8 @@ struct Opt {
     int thr = 8;                 // lazy-rescale threshold of the tracked pass, log2 units
     int r = 1;                   // 32-row query groups per wave: 1 = 8 waves, two per SIMD; 2 = 4 waves (experimental arm)
     bool asm_mfma = false;       // inline-asm MFMAs with dictated register classes (needed by r = 2)
-    bool valu_first = true;      // phase-A slots issue their softmax slice before the MFMA
+    int valu_first = -1;         // phase-A slots issue their softmax slice before the MFMA: +2 % on the 32x32x16 engine (it covers the
+                                 // fragment's LDS latency), -1 % on the 16x16x32 engine.  -1: on for 32x32x16, off for 16x16x32
     bool persist = true;         // one workgroup per CU walks a static list of units (see work_unit)
     bool lds_epilogue32 = true;  // fp32 outputs leave through LDS as whole 256-byte row pieces
     bool pad = false;            // the tensors' head dimension is smaller than D: rows are zero-padded on the fly
@@ -51,6 +52,13 @@ struct Opt {
                                  // a higher clock on that shape (power).  -1: on for bf16 inputs with r = 1
     int sum_mfma = -1;           // 16x16x32 engine: row sums from ONES.P^T MFMAs (sums the bf16-rounded weights) instead of one v_add_f32
                                  // per score.  -1: on (the library turns it off in the kernels that return the LSE)
+    int stream = 0;              // REJECTED BY MEASUREMENT (kept as an arm: tests/fa_tune "unit streaming").  16x16x32 engine, persistent grid:
+                                 // ONE continuous K/V tile stream across the units of a workgroup -- a unit's last iteration scores the next
+                                 // unit's tile 0 (its QK^T phase otherwise runs on garbage), the next unit's tiles 0, 1 and Q arrive under the
+                                 // current unit's last iterations, the epilogue gets LDS of its own: no per-unit prologue (stream_units16).
+                                 // Bitwise-identical results, per-unit fixed cost 5.1k -> 1.2k cycles, but the tile loop itself got 4-15 %
+                                 // slower in every form tried (the seam's conditional code inside the loop body costs hipcc's schedule more
+                                 // than the prologues cost): -3 % non-causal, -4 % causal (profiles/r02_tune_g_unit_streaming.log)
     bool p_f16 = false;          // 16x16x32 engine: weights rounded to fp16 (11 significant bits) instead of bf16 (8), V staged as fp16, P.V
                                  // on v_mfma_f32_16x16x32_f16: the precision option behind FA_FLAG_F16_WEIGHTS (needs |V| <= 65504)
     // ---- rejected by measurement, kept as arms of the tuner (numbers: causal / non-causal headline shape) ----
@@ -74,7 +82,7 @@ struct KernelCfg {
     static constexpr bool CAUSAL = CAUSAL_;
     using OutT = OutT_;
     static constexpr int ESZ = ESZ_;                 // bytes per Q/K/V element: 2 = bf16, 1 = fp8 e4m3fn
-    static constexpr bool STAMP = O.stamp, OPTIMISTIC = O.optimistic, ASM_MFMA = O.asm_mfma, VALU_FIRST = O.valu_first;
+    static constexpr bool STAMP = O.stamp, OPTIMISTIC = O.optimistic, ASM_MFMA = O.asm_mfma;
     static constexpr bool PERSIST = O.persist, LDS_EPILOGUE32 = O.lds_epilogue32, PK = O.pk, DOT2 = O.dot2;
     static constexpr bool SKIP_LAST_QK = O.skip_last_qk;
     static constexpr bool COALESCED_Q = (O.coalesced_q < 0 ? D_ == 128 : O.coalesced_q != 0) && O.r == 1 && !O.pad;
@@ -84,7 +92,9 @@ struct KernelCfg {
     static constexpr bool M16 = (O.m16 < 0 ? true : O.m16 != 0) && ESZ_ == 2 && O.r == 1 && !O.asm_mfma && O.ring == 3 && !O.skip_last_qk &&
                                 !O.pk && !O.dot2 && O.wg == 1;
     static constexpr bool SUM_MFMA = M16 && (O.sum_mfma < 0 ? true : O.sum_mfma != 0);
+    static constexpr bool VALU_FIRST = O.valu_first < 0 ? !M16 : O.valu_first != 0;
     static constexpr bool P_F16 = M16 && O.p_f16;
+    static constexpr bool STREAM = M16 && O.persist && O.optimistic && O.stream != 0;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
     static constexpr int NWAVES = 8 / O.r;           // waves per workgroup (256 query rows)
@@ -94,7 +104,12 @@ struct KernelCfg {
     static_assert(RING == 3 || RING == 4, "3- or 4-slot ring");
     static constexpr int RING_BYTES = RING * TileGeom<D_, ESZ_>::SLOT;
     // the fp32 LDS epilogue stages 256 rows x 64 floats: more than the ring at d = 64
-    static constexpr int LDS_BYTES = (O.lds_epilogue32 && sizeof(OutT_) == 4 && RING_BYTES < 65536) ? 65536 : RING_BYTES;
+    // streamed units: the epilogue's staging regions (per wave 16 rows x D 2-byte outputs, or x 64 floats) sit BEHIND the ring
+    static constexpr int EP_WAVE_BYTES = 16 * (sizeof(OutT_) == 2 ? D_ * 2 : 256);
+    static constexpr int EP_BYTES = 8 * EP_WAVE_BYTES;
+    static constexpr int LDS_BYTES = STREAM ? RING_BYTES + EP_BYTES
+                                            : ((O.lds_epilogue32 && sizeof(OutT_) == 4 && RING_BYTES < 65536) ? 65536 : RING_BYTES);
+    static_assert(LDS_BYTES <= 163840 - 256, "160 KiB of LDS per CU, 256 bytes of which __syncthreads_or takes statically");
 };
 
 // What the library launches: the defaults of Opt.
@@ -288,12 +303,219 @@ struct UnitCtx {
     }
 };
 
+// Streamed units (C::STREAM; 16x16x32 engine, optimistic pass).  A workgroup's units form ONE tile stream: iteration t of a unit
+// with n tiles stages stream element t+2 -- the next unit's tile t+2-n once t+2 >= n -- and its LAST iteration, whose QK^T phase
+// has no tile of its own left to score, scores the next unit's tile 0 against the next unit's Q (requested between the two
+// phases of the second-to-last iteration, when this unit's Q is dead).  At the seam only the finiteness check, the epilogue
+// (through LDS regions of its own, behind the ring) and the row max of the new tile 0 remain; the ring rotation just continues.
+// Per unit this removes: Q load + LDS trip, staging of tiles 0 and 1 with their two barriers, and the unoverlapped S(0) = K(0).Q^T.
+// A unit that fails the finiteness check is recomputed from scratch by the tracked pass (attention_pass<C, true>), after which
+// -- as after a unit with fewer than two tiles -- the stream restarts with a full prologue.
+template <class C>
+__device__ __forceinline__ void stream_units16(const Params& p, lds_ptr smem) {
+    constexpr int D = C::D, ESZ = C::ESZ, KVBLK = 64, WROWS = 32;
+    using OutT = typename C::OutT;
+    using WC = WaveCompute16<C>;
+    using G = TileGeom<D, ESZ>;
+    constexpr int SLOT = G::SLOT, KT = G::K_TILE;
+    int g, qb, round = 0;
+    if (!work_unit<C>(p, 0, g, qb)) return;
+    unsigned long long t_kernel0 = 0;
+    if constexpr (C::STAMP) t_kernel0 = cycle_stamp();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = p.S, Sk = p.Sk;
+    const int64_t qSb = p.qS * ESZ, kSb = p.kS * ESZ, vSb = p.vS * ESZ, oSb = p.oS * (int64_t)sizeof(OutT);
+    const int row_bytes = C::PAD ? p.d * ESZ : D * ESZ, orow_bytes = C::PAD ? p.d * (int)sizeof(OutT) : D * (int)sizeof(OutT);
+    const float c = p.scale_log2;
+
+    // A unit's pointers and counts are a pure function of (p, round): they are recomputed where they are needed (seam code)
+    // instead of living in registers across the tile loop -- the loop keeps only n_tiles, my_tiles and q_row0.
+    auto unit_of = [&](int rnd, UnitCtx<C>& u) {
+        int gg, qq;
+        if (!work_unit<C>(p, rnd, gg, qq)) return false;
+        u.set(p, gg, qq, wave);
+        return true;
+    };
+    WC w;
+    typename WC::Stage st;
+    {
+        UnitCtx<C> u0;
+        u0.set(p, g, qb, wave);
+        st.init(u0.Kh, u0.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
+        st.load_all(0);                                 // tile 0 and Q travel together (one HBM round trip)
+        if constexpr (C::COALESCED_Q) w.load_q_rows(u0.Qh, qSb, u0.q_row0, S, lane);
+        else w.load_q(u0.Qh, qSb, u0.q_row0, S, lane, row_bytes);
+    }
+    bool q_as_rows = C::COALESCED_Q;                 // only the workgroup's first unit takes the coalesced form (the ring is empty then)
+    unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Scores16 sA, sB;
+    bool fresh = true;                               // this unit starts with a full prologue
+    int so_cur = 0, so_nxt = SLOT, so_wr = 2 * SLOT; // ring slot byte offsets of stream elements t, t+1, t+2
+
+    while (true) {
+        // lane-derived values are unit-invariant: an opaque copy keeps hipcc from hoisting (and spilling) them
+        int lane_u = lane;
+        asm volatile("" : "+v"(lane_u));
+        const int kbase = k16_read_base(lane_u), vbase = v16_read_base<D>(lane_u);
+        int q_row0, n_tiles, my_tiles;
+        {
+            UnitCtx<C> cu;
+            unit_of(round, cu);
+            q_row0 = cu.q_row0; n_tiles = cu.n_tiles; my_tiles = cu.my_tiles;
+        }
+        auto needs_mask = [&](int t) { return (C::CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > Sk); };
+        unsigned long long t_u0 = 0;
+        if constexpr (C::STAMP) t_u0 = cycle_stamp();
+
+        // ---------- start of a unit ----------
+        if (fresh) {
+            w.pin_q();
+            if (q_as_rows) {
+                static_assert(!C::COALESCED_Q || G::SLOT + 256 * D * ESZ <= C::LDS_BYTES, "Q staging regions must fit behind slot 0");
+                if constexpr (C::COALESCED_Q) {
+                    w.q_rows_to_fragments(smem + G::SLOT + wave * (WROWS * D * ESZ), lane_u);
+                    w.pin_q();
+                }
+                q_as_rows = false;
+            }
+            st.write_all(smem);
+            __syncthreads();
+            st.load_all(1);          // past-the-end tiles read as zeros (buffer range check)
+            if (my_tiles > 0) w.qk_all(smem, kbase, sA);
+            st.write_all(smem + SLOT);
+            __syncthreads();
+            so_cur = 0; so_nxt = SLOT; so_wr = 2 * SLOT;
+        }
+        w.init();
+        if (my_tiles > 0) {
+            if (needs_mask(0)) w.mask(sA, 0, q_row0, Sk, lane_u);
+            w.first_max(sA, c);   // m = row max of tile 0 (the reference of the optimistic pass)
+        }
+        if constexpr (C::STAMP) acc[9] += cycle_stamp() - t_u0;
+
+        // the unit after this one: its heads feed the tail of this unit's tile stream
+        bool more, stream, next_live;
+        {
+            UnitCtx<C> nx;
+            more = unit_of(round + 1, nx);
+            stream = more && n_tiles >= 2;
+            next_live = stream && nx.my_tiles > 0;
+            if (stream) st.set_next(nx.Kh, nx.Vh, n_tiles);
+        }
+
+        // ---------- tile loop ----------
+        auto step = [&](int t, Scores16& cs, Scores16& ns) {
+            unsigned long long t0 = 0, t4 = 0, t6 = 0;
+            if constexpr (C::STAMP) t0 = cycle_stamp();
+            const int kind = t + 1 < my_tiles ? 0 : (t < my_tiles ? 1 : 2);
+            const bool q_now = next_live && t == n_tiles - 2, last = t == n_tiles - 1;
+            auto fetch_next_q = [&]() {
+                if (q_now) {   // wave-uniform, once per unit: the next unit's Q fragments replace this unit's (dead from here on)
+                    UnitCtx<C> nx;
+                    unit_of(round + 1, nx);
+                    w.load_q(nx.Qh, qSb, nx.q_row0, S, lane_u, row_bytes);
+                }
+            };
+            if (kind != 2) {
+                const bool has_next = kind == 0;
+                w.template tile_step<false, false>(st, t + 2, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cs, ns, has_next,
+                                                   has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, Sk, lane_u);
+                fetch_next_q();
+            } else {
+                // past this wave's causal diagonal: it stages its share of the stream, and at the seam fetches / scores for the next unit
+                st.load_all(st.select(t + 2));
+                st.write_all(smem + so_wr);
+                fetch_next_q();
+                if (last && next_live) {
+                    w.pin_q();
+                    w.qk_all(smem + so_nxt, kbase, ns);
+                }
+            }
+            if constexpr (C::STAMP) t4 = cycle_stamp();
+            if constexpr (!C::DBG_NOBAR) __syncthreads();
+            if constexpr (C::STAMP) {
+                t6 = cycle_stamp();
+                if (kind != 2) { acc[1] += w.t_mid - t0; acc[2] += w.t_end - w.t_mid; acc[3] += t4 - w.t_end; acc[6] += 1; }
+                acc[5] += t6 - t4;
+            }
+            const int tmp = so_cur;
+            so_cur = so_nxt;
+            so_nxt = so_wr;
+            so_wr = tmp;
+        };
+        for (int t = 0; t < n_tiles; t += 2) {
+            step(t, sA, sB);
+            if (t + 1 < n_tiles) step(t + 1, sB, sA);
+        }
+        if (next_live && (n_tiles & 1)) sA = sB;   // the next unit's S(0) continues in sA
+
+        // ---------- end of the unit ----------
+        unsigned long long tc0 = 0;
+        if constexpr (C::STAMP) tc0 = cycle_stamp();
+        const bool bad = __syncthreads_or(my_tiles > 0 && w.not_finite()) != 0;
+        if constexpr (C::STAMP) acc[10] += cycle_stamp() - tc0;
+        UnitCtx<C> cu;
+        unit_of(round, cu);
+        if (bad) {
+            // a score outran the optimistic reference by more than the headroom: the tracked pass recomputes the unit from scratch
+            st.init(cu.Kh, cu.Vh, kSb, vSb, Sk, wave, lane_u, row_bytes);
+            w.load_q(cu.Qh, qSb, q_row0, S, lane_u, row_bytes);
+            w.pin_q();
+            RowSink sink{cu.Oh, cu.lse_head, oSb, orow_bytes, false};
+            attention_pass<C, true>(p, w, st, smem, n_tiles, my_tiles, q_row0, lane_u, acc, false, sink);
+            WC::zero(sA);   // (the stream restarts below: tell the register allocator that no score buffer lives across the tracked pass)
+        }
+        unsigned long long t_ep0 = 0;
+        if constexpr (C::STAMP) t_ep0 = cycle_stamp();
+        {
+            int lane_e = lane;   // (the epilogue's ~40 per-lane addresses must be recomputed here, not hoisted and spilled)
+            asm volatile("" : "+v"(lane_e));
+            lds_ptr ep = smem + C::RING_BYTES;
+            lds_ptr mine = ep + wave * C::EP_WAVE_BYTES;
+            if constexpr (sizeof(OutT) == 2) {
+                if (cu.wave_live) w.template store_o_lds<OutT>(mine, cu.Oh, cu.lse_head, oSb, q_row0, S, lane_e, orow_bytes);
+            } else {
+                if (cu.wave_live) w.template store_o_lds32<OutT>(mine, cu.Oh, cu.lse_head, oSb, q_row0, S, lane_e, orow_bytes);
+            }
+        }
+        if constexpr (C::STAMP) acc[4] += cycle_stamp() - t_ep0;
+        if (!more) break;
+        ++round;
+        if (stream && !bad) {
+            st.advance();
+            fresh = false;
+        } else {
+            // (every wave left the ring at the barrier inside __syncthreads_or / the tracked pass: it may be refilled)
+            UnitCtx<C> nx;
+            unit_of(round, nx);
+            st.init(nx.Kh, nx.Vh, kSb, vSb, Sk, wave, lane_u, row_bytes);
+            st.load_all(0);
+            w.load_q(nx.Qh, qSb, nx.q_row0, S, lane_u, row_bytes);
+            fresh = true;
+        }
+    }
+    if constexpr (C::STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store tail
+        acc[0] = cycle_stamp() - t_kernel0;
+        if (lane == 0 && p.dbg) {
+#pragma unroll
+            for (int k = 0; k < 11; ++k) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + k] = acc[k];
+            p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 11] = 1;
+        }
+    }
+}
+
 template <class C>
 __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_kernel(const Params p) {
     constexpr int D = C::D, ESZ = C::ESZ;
     using OutT = typename C::OutT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     lds_ptr smem = (lds_ptr)smem_raw;
+    if constexpr (C::STREAM) {
+        stream_units16<C>(p, smem);
+        return;
+    }
 
     int g, qb, round = 0;
     if (!work_unit<C>(p, 0, g, qb)) return;

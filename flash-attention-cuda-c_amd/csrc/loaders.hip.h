@@ -124,6 +124,10 @@ struct BufStage {
     static constexpr int NW = LOADS + LOADS * VW;                // LDS writes per thread per tile
     static_assert(8 % NWAVES == 0, "NWAVES must divide the 8 key groups of a tile");
     __amdgpu_buffer_rsrc_t krsrc, vrsrc;
+    // Unit streaming (kernel_bf16.hip.h: stream_units16): tile indices >= t_switch belong to the NEXT unit's K / V (tile
+    // t - t_switch of the heads at k2 / v2), so one continuous tile stream crosses the seam between two units.
+    const char *k1 = nullptr, *v1 = nullptr, *k2 = nullptr, *v2 = nullptr;
+    int t_switch = 0x7fffffff, krec = 0, vrec = 0;
     int koff, voff;        // per-lane byte offset of load 0 inside a tile (constant)
     int klds, vlds;        // per-lane LDS byte offset of write 0 inside the K / V image
     int ktile, vtile;      // bytes per 64-key tile step (scalar)
@@ -135,8 +139,13 @@ struct BufStage {
                                          int wave, int lane, int row_bytes = G::ROWB) {
         // descriptor inputs are blockIdx / kernarg derived -> wave-uniform; num_records = the head's extent, to
         // the last byte of its last row (a strided view's rows are followed by other heads' data, or by nothing)
-        krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (int)((S - 1) * kS_bytes + row_bytes), 0x00020000);
-        vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (int)((S - 1) * vS_bytes + row_bytes), 0x00020000);
+        krec = (int)((S - 1) * kS_bytes + row_bytes);
+        vrec = (int)((S - 1) * vS_bytes + row_bytes);
+        k1 = Kh;
+        v1 = Vh;
+        krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, krec, 0x00020000);
+        vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, vrec, 0x00020000);
+        t_switch = 0x7fffffff;
         ktile = (int)(64 * kS_bytes);
         vtile = (int)(64 * vS_bytes);
         kgrp = (int)(8 * kS_bytes);
@@ -157,6 +166,27 @@ struct BufStage {
                 vok[hf] = (vc + 8 * hf) * 16 < row_bytes;
             }
         }
+    }
+    // the stream continues into the next unit (same shapes and strides, other heads) from tile index `at` on
+    __device__ __forceinline__ void set_next(const char* Kh_next, const char* Vh_next, int at) {
+        k2 = Kh_next;
+        v2 = Vh_next;
+        t_switch = at;
+    }
+    // Once per iteration, before its loads: point the descriptors at the unit that owns stream element t and return the tile
+    // index inside that unit.  Scalar selects, no branch (a branch inside the slot sequence splits its basic block and lets hipcc
+    // sink the softmax arithmetic of the slots before it behind it).
+    __device__ __forceinline__ int select(int t) {
+        const bool nx = t >= t_switch;
+        krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(nx ? k2 : k1), 0, krec, 0x00020000);
+        vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(nx ? v2 : v1), 0, vrec, 0x00020000);
+        return nx ? t - t_switch : t;
+    }
+    // ... and the next unit becomes the current one: tile indices restart at 0
+    __device__ __forceinline__ void advance() {
+        k1 = k2;
+        v1 = v2;
+        t_switch = 0x7fffffff;
     }
     __device__ __forceinline__ static u32x4 keep_if(bool ok, u32x4 v) {
         const u32x4 z = {0u, 0u, 0u, 0u};

@@ -6,10 +6,11 @@
 // Here the sizes are what the MI355X kernels are built around:
 //
 //   Br (query rows / workgroup): 8 waves x 32 rows = 256 for the MFMA kernels.  32 rows per wave
-//      is one 32x32 MFMA tile; 8 waves = 2 per SIMD share every K/V tile staged in LDS, which
-//      halves L2->LDS traffic per FLOP against a 4-wave workgroup.  Register budget per lane at
-//      2 waves/SIMD is 256: O^T accumulators 16*d/32, Q fragments 4*d/16, scores 32, P 16,
-//      staging 8*d/64 -- about 200 at d = 128.
+//      are two 16-row query groups of the 16x16x32 engine (bf16) or one 32x32 tile of the 32x32x16
+//      engine (fp8); 8 waves = 2 per SIMD share every K/V tile staged in LDS, which halves L2->LDS
+//      traffic per FLOP against a 4-wave workgroup.  Register budget per lane at 2 waves/SIMD is
+//      256: O^T accumulators d/2, Q fragments d/4, scores 2 x 32 (ping-pong), P 16, K / V^T fragment
+//      windows 28, staging 16 -- about 250 at d = 128.
 //   Bc (keys / tile): 64.  Two 32-key score tiles per wave; K + V tile = 32 KiB at d = 128,
 //      a 3-slot ring = 96 KiB of the CU's 160 KiB LDS.
 //   Grid: persistent, one workgroup per CU walking ceil(units / CUs) units (kernel_bf16.hip.h: work_unit).

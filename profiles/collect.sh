@@ -8,6 +8,7 @@
 # then profiles/summarize.py turns them into small files under gpurun_out/ to be copied into profiles/.
 # The program itself follows `--` (no env / bash -c hop: the profiler initialises the GPU before the program starts).
 set -e
+mkdir -p ${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out
 TAG=${1:?tag}
 WL=${2:-cfg2}
 cd /tmp && export TMPDIR=/tmp

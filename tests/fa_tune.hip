@@ -76,6 +76,16 @@ static std::vector<Variant> make_variants() {
     using T = __bf16;
     std::vector<Variant> v;
     v.push_back({"production (16x16x32 MFMAs)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
+#ifdef FA_TUNE_SWEEP
+    v.push_back({"npre 6", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6}>>});
+    v.push_back({"npre 8", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 8}>>});
+    v.push_back({"vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3}>>});
+    v.push_back({"vpre 4", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 4}>>});
+    v.push_back({"npre 6 vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3}>>});
+    v.push_back({"npre 2 vpre 1", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 2, .vpre = 1}>>});
+    v.push_back({"VALU-first slots", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = 1}>>});
+#endif
+    v.push_back({"unit streaming (no per-unit prologue)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.stream = 1}>>});
     v.push_back({"fp16 weights (FA_FLAG_F16_WEIGHTS)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>});
     v.push_back({"exact row sums (the LSE instantiation)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.sum_mfma = 0}>>});
     v.push_back({"32x32x16 MFMAs (round-1 production)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0}>>});
@@ -102,7 +112,7 @@ static std::vector<Variant> make_variants() {
     v.push_back({"one unit per workgroup (r01 a-j)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.persist = false}>>});
     v.push_back({"tracked only (persistent)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.optimistic = false}>>});
     v.push_back({"persistent npre6 vpre3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3}>>});
-    v.push_back({"MFMA-first slots (old order)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = false}>>});
+    v.push_back({"MFMA-first slots (old order)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = 0}>>});
     v.push_back({"one unit per workgroup STAMP", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.stamp = true, .persist = false}>>});
 #endif
     v.push_back({"production STAMP", launch_cfg<ProdCfg<D, CAUSAL, T, 2, true>>});
