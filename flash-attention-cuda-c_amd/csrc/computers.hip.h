@@ -170,15 +170,19 @@ struct WaveCompute {
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) kf[i] = k_read(kimg, kbase, i);
     }
+    // Fragment f = (k-step, 32-key half).  Opt::qk_pair_order (bf16): half-major inside a k-step, (u, kt) = (f/2, f%2), so
+    // two consecutive MFMAs take the SAME Q fragment (one operand does not toggle); otherwise k-step-major, (f%FPH, f/FPH).
+    __host__ __device__ static constexpr int frag_u(int f) { return C::QK_PAIR ? f / 2 : f % FPH; }
+    __host__ __device__ static constexpr int frag_kt(int f) { return C::QK_PAIR ? f % 2 : f / FPH; }
     __device__ __forceinline__ u32x4 k_read(lds_ptr kimg, int kbase, int f) const {
-        return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + (f % FPH) * 2048 + (f / FPH) * 512));
+        return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + frag_u(f) * 2048 + frag_kt(f) * 512));
     }
     // QK^T MFMA of fragment f, sub-step sub (fp8 only), row group r.  kprev = the fragment before kfrag (MX form only).
     template <int F, int SUB, int RG>
     __device__ __forceinline__ void qk_mfma(const u32x4& kprev, const u32x4& kfrag, Scores<R>& n) const {
-        const u32x4& q = qf[RG][F % FPH];
-        f32x16& acc = n.s[RG][F / FPH];
-        constexpr bool first = (F % FPH == 0) && SUB == 0;   // first MFMA of this accumulation chain
+        const u32x4& q = qf[RG][frag_u(F)];
+        f32x16& acc = n.s[RG][frag_kt(F)];
+        constexpr bool first = (frag_u(F) == 0) && SUB == 0;   // first MFMA of this accumulation chain
         if constexpr (C::MXQK) {
             // fragments (F-1, F) = 64 contraction elements in ONE block-scaled MFMA, issued in the last slot of
             // the pair; the pair's other three slots carry only their softmax slice

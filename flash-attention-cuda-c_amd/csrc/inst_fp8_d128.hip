@@ -22,13 +22,12 @@ hipError_t by_out(const Params& p, const fa_launch_plan& plan, int o_dtype, hipS
     return launch_mfma<ProdCfg<D, CAUSAL, _Float16, ESZ, false, PAD, LSE>>(p, plan, st);
 }
 
-template <bool PAD>
+template <bool PAD, int ESZ_ = 1>
 hipError_t by_causal_lse(const Params& p, const fa_launch_plan& plan, bool causal, int o_dtype, hipStream_t st) {
-    // bf16 inputs: a call that also wants the LSE runs the instantiation that sums the unrounded weights; the fp8 kernels
-    // (32x32x16 engine) sum unrounded weights anyway
-    const bool lse = 1 == 2 && p.lse != nullptr;
-    if constexpr (1 == 2) {
-        if (lse) return causal ? by_out<true, PAD, true>(p, plan, o_dtype, st) : by_out<false, PAD, true>(p, plan, o_dtype, st);
+    // bf16 inputs without the mask (16x16x32 engine): a call that also wants the LSE runs the instantiation that sums the
+    // unrounded weights.  The causal and the fp8 kernels (32x32x16 engine) sum unrounded weights anyway.
+    if constexpr (ESZ_ == 2) {
+        if (p.lse != nullptr && !causal) return by_out<false, PAD, true>(p, plan, o_dtype, st);
     }
     return causal ? by_out<true, PAD, false>(p, plan, o_dtype, st) : by_out<false, PAD, false>(p, plan, o_dtype, st);
 }

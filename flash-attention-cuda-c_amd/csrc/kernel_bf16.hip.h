@@ -58,7 +58,10 @@ struct Opt {
                                  // current unit's last iterations, the epilogue gets LDS of its own: no per-unit prologue (stream_units16).
                                  // Bitwise-identical results, per-unit fixed cost 5.1k -> 1.2k cycles, but the tile loop itself got 4-15 %
                                  // slower in every form tried (the seam's conditional code inside the loop body costs hipcc's schedule more
-                                 // than the prologues cost): -3 % non-causal, -4 % causal (profiles/r02_tune_g_unit_streaming.log)
+                                 // than the prologues cost): -3 % non-causal, -4 % causal (profiles/r02_tune_g_unit_streaming.log).  With the
+                                 // seam's two iterations peeled out of the loop instead (five inlined copies of the tile step) the register
+                                 // allocator spills 1 KB per lane into the loop: -33 % (profiles/r02_tune_h_unit_streaming_peeled.log)
+    bool qk_pair_order = false;  // 32x32x16 engine, bf16: QK^T fragments ordered so that consecutive MFMAs share their Q fragment
     bool p_f16 = false;          // 16x16x32 engine: weights rounded to fp16 (11 significant bits) instead of bf16 (8), V staged as fp16, P.V
                                  // on v_mfma_f32_16x16x32_f16: the precision option behind FA_FLAG_F16_WEIGHTS (needs |V| <= 65504)
     // ---- rejected by measurement, kept as arms of the tuner (numbers: causal / non-causal headline shape) ----
@@ -72,7 +75,9 @@ struct Opt {
     bool skip_last_qk = false;   // a wave's last tile step without the (unused) QK^T MFMAs: -1..-2 %
     // ---- TIMING EXPERIMENTS ONLY (wrong results by construction): bit 0 no per-tile barrier, bit 1 no global loads in
     // the tile loop, bit 2 P.V takes a constant P (no VALU -> MFMA dependency), bit 3 every 32x32x16 MFMA replaced by two
-    // 16x16x32 on the same operand registers (same FLOPs, same dataflow shape: what would that MFMA shape cost / save?) ----
+    // 16x16x32 on the same operand registers (same FLOPs, same dataflow shape: what would that MFMA shape cost / save?), bit 4 waves
+    // 4-7 run the P.V phase BEFORE the QK^T phase inside each iteration (the two waves of a SIMD in complementary phases: what would
+    // a half-iteration stagger be worth?) ----
     int dbg = 0;
 };
 
@@ -94,6 +99,7 @@ struct KernelCfg {
     static constexpr bool SUM_MFMA = M16 && (O.sum_mfma < 0 ? true : O.sum_mfma != 0);
     static constexpr bool VALU_FIRST = O.valu_first < 0 ? !M16 : O.valu_first != 0;
     static constexpr bool P_F16 = M16 && O.p_f16;
+    static constexpr bool QK_PAIR = O.qk_pair_order && ESZ_ == 2 && !M16;
     static constexpr bool STREAM = M16 && O.persist && O.optimistic && O.stream != 0;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
@@ -113,8 +119,11 @@ struct KernelCfg {
 };
 
 // What the library launches: the defaults of Opt.
+// Which engine: without the mask the kernel is power-bound and the 16x16x32 engine's cheaper MFMAs win (+0.9 ... +4.4 % over five
+// boxes); under the causal mask the idle stretches (per-unit prologue / epilogue, diagonal block) leave power to spare, cycles
+// decide, and the 32x32x16 engine's lower issue pressure wins (16x16x32: -6.8 ... +1.3 %, mean -2.3 %).  DESIGN.md section 4.
 template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false, bool PAD = false, bool LSE = false>
-using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, Opt{.stamp = STAMP, .pad = PAD, .sum_mfma = LSE ? 0 : -1}>;
+using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, Opt{.stamp = STAMP, .pad = PAD, .m16 = CAUSAL ? 0 : -1, .sum_mfma = LSE ? 0 : -1}>;
 
 // The per-wave compute engine of a configuration: 16x16x32 MFMAs (computers16.hip.h) or 32x32x16 (computers.hip.h).
 template <class C>

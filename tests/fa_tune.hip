@@ -75,7 +75,8 @@ template <int D, bool CAUSAL>
 static std::vector<Variant> make_variants() {
     using T = __bf16;
     std::vector<Variant> v;
-    v.push_back({"production (16x16x32 MFMAs)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
+    v.push_back({"production (16x16x32 non-causal, 32x32x16 causal)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
+    v.push_back({"16x16x32 MFMAs", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1}>>});
 #ifdef FA_TUNE_SWEEP
     v.push_back({"npre 6", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6}>>});
     v.push_back({"npre 8", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 8}>>});
@@ -106,6 +107,7 @@ static std::vector<Variant> make_variants() {
     v.push_back({"EXPERIMENT P.V takes constant P (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 4}>>});
     v.push_back({"EXPERIMENT no barrier + no loads + constant P (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 7}>>});
 #endif
+    v.push_back({"32x32x16, QK^T pairs share their Q fragment", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0, .qk_pair_order = true}>>});
     v.push_back({"EXPERIMENT two 16x16x32 per 32x32x16 (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0, .dbg = 8}>>});
     v.push_back({"R=2 asm persistent (experimental)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.r = 2, .asm_mfma = true}>>});
 #ifdef FA_TUNE_FULL
