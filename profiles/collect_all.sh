@@ -6,6 +6,7 @@
 #   <tag>_kernel_stats_<workload>.csv   rocprofv3 --kernel-trace --stats of `python3 bench.py --workload <workload> ...`
 #   <tag>_hbm_traffic_<workload>.json   FETCH_SIZE / WRITE_SIZE (separate --pmc passes, FETCH doubled: gfx950) + csrc sha256
 #   <tag>_sq_counters_<workload>.json   MFMA busy, clock, LDS bank conflicts
+#   <tag>_kernel_timed_<workload>.json  the same trace, averaged over the timed region only (profiles/timed_region.py)
 # Copy that directory's files into profiles/ and commit them.
 TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -20,5 +21,7 @@ for WL in cfg2 cfg2nc cfg1 cfg3; do
   done
   # the bench line printed under the --stats pass (its own HIP-event kernel time, to compare with the CSV's average)
   grep -h '^{' $REPO/gpurun_out/${TAG}_${WL}_stats.log | tail -1 > $OUT/${TAG}_bench_under_rocprof_stats_${WL}.json
+  # average kernel duration over the bench's TIMED region (its last 20 dispatches) from the same trace
+  (cd $REPO && python3 profiles/timed_region.py gpurun_out/${TAG}_${WL}_stats 20 > $OUT/${TAG}_kernel_timed_${WL}.json)
 done
 ls -la $OUT
