@@ -60,10 +60,11 @@ struct WaveCompute {
     static constexpr int NE = 32 * R;              // score elements per lane per tile
     static constexpr int SPAN = SA + (3 * SB) / 4; // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
-    using Stage = BufStage<D, ESZ, 8 / R, C::PAD>;
+    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, false, true>, BufStage<D, ESZ, C::NWAVES, C::PAD>>;
     using ScoresT = Scores<R>;
     static constexpr int NL = Stage::NL, NW = Stage::NW;
-    static_assert(2 * NL <= SA && 2 * NW <= SB / 2 + 1, "staging does not fit the slot plan");
+    static constexpr int WSTEP = 2 * NW <= SB / 2 + 1 ? 2 : 1;   // LDS writes sit in every WSTEP-th slot of the second half of phase B
+    static_assert(2 * NL <= SA && WSTEP * (NW - 1) < SB - SB / 2, "staging does not fit the slot plan");
 
     // ---- state that lives across tiles ----
     u32x4 qf[R][FPH];  // Q fragments (16 bytes each: one bf16 MFMA operand, or two fp8 operands)
@@ -175,7 +176,8 @@ struct WaveCompute {
     __host__ __device__ static constexpr int frag_u(int f) { return C::QK_PAIR ? f / 2 : f % FPH; }
     __host__ __device__ static constexpr int frag_kt(int f) { return C::QK_PAIR ? f % 2 : f / FPH; }
     __device__ __forceinline__ u32x4 k_read(lds_ptr kimg, int kbase, int f) const {
-        return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + frag_u(f) * 2048 + frag_kt(f) * 512));
+        if constexpr (C::DMA) return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + frag_kt(f) * (4 * Stage::KBLK) + frag_u(f) * 256));
+        else return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + frag_u(f) * 2048 + frag_kt(f) * 512));
     }
     // QK^T MFMA of fragment f, sub-step sub (fp8 only), row group r.  kprev = the fragment before kfrag (MX form only).
     template <int F, int SUB, int RG>
@@ -421,8 +423,8 @@ struct WaveCompute {
             exp_slot<SA + J>(cur, c);
             if constexpr (TRACK && J < SB / 2) max3_slot<J>(nxt);
             if constexpr (TRACK && J == SB / 2) decide(c);
-            if constexpr (J >= SB / 2 && ((J - SB / 2) & 1) == 0 && (J - SB / 2) / 2 < NW)
-                st.template write<(J - SB / 2) / 2>(wr_slot);
+            if constexpr (J >= SB / 2 && (J - SB / 2) % WSTEP == 0 && (J - SB / 2) / WSTEP < NW)
+                st.template write<(J - SB / 2) / WSTEP>(wr_slot);
             __builtin_amdgcn_sched_barrier(0);
             slots_b<TRACK, J + 1>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         }
@@ -438,6 +440,7 @@ struct WaveCompute {
                                               int kbase, int vbase, float c, const Scores<R>& cur, Scores<R>& nxt,
                                               bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane,
                                               lds_ptr k_next2 = nullptr) {
+        st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             sum_a[r] = sum_b[r] = 0.f;

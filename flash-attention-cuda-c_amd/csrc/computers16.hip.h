@@ -60,12 +60,13 @@ struct WaveCompute16 {
     static constexpr int NE = 32;                  // score elements per lane per tile
     static constexpr int SPAN = SA + SB / 2;       // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
-    using Stage = BufStage<D, ESZ, 8, C::PAD, true, C::P_F16>;
+    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, true, false>, BufStage<D, ESZ, C::NWAVES, C::PAD, true, C::P_F16>>;
     // the P.V operand type: bf16, or fp16 with the fp16-weights option (weights rounded to 11 bits instead of 8; V staged as fp16)
     using pv_t = std::conditional_t<C::P_F16, f16x8, bf16x8>;
     using ScoresT = Scores16;
     static constexpr int NL = Stage::NL, NW = Stage::NW;
-    static_assert(2 * NL <= SA && 2 * NW <= SB / 2 + 1, "staging does not fit the slot plan");
+    static constexpr int WSTEP = 2 * NW <= SB / 2 + 1 ? 2 : 1;   // LDS writes sit in every WSTEP-th slot of the second half of phase B
+    static_assert(2 * NL <= SA && WSTEP * (NW - 1) < SB - SB / 2, "staging does not fit the slot plan");
 
     // ---- state that lives across tiles ----
     u32x4 qf[QG][KS];   // Q fragments
@@ -162,7 +163,8 @@ struct WaveCompute16 {
 
     // K fragment f = (key group f / KS, k-step f % KS)
     __device__ __forceinline__ u32x4 k_read(lds_ptr kimg, int kbase, int f) const {
-        return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + (f % KS) * 4096 + (f / KS) * 256));
+        if constexpr (C::DMA) return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + (f / KS) * (2 * Stage::KBLK) + (f % KS) * 512));
+        else return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + (f % KS) * 4096 + (f / KS) * 256));
     }
     __device__ __forceinline__ void k_prefetch(lds_ptr, int) {}   // (4-slot-ring arm of the 32x32 kernel only)
     template <int F, int QGI>
@@ -310,8 +312,8 @@ struct WaveCompute16 {
             exp_slot<SA + J>(cur, c);
             if constexpr (TRACK && J < SB / 2) max3_slot<J>(nxt);
             if constexpr (TRACK && J == SB / 2) decide(c);
-            if constexpr (J >= SB / 2 && ((J - SB / 2) & 1) == 0 && (J - SB / 2) / 2 < NW)
-                st.template write<(J - SB / 2) / 2>(wr_slot);
+            if constexpr (J >= SB / 2 && (J - SB / 2) % WSTEP == 0 && (J - SB / 2) / WSTEP < NW)
+                st.template write<(J - SB / 2) / WSTEP>(wr_slot);
             __builtin_amdgcn_sched_barrier(0);
             slots_b<TRACK, J + 1>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         }
@@ -333,6 +335,7 @@ struct WaveCompute16 {
             sum_a[qg] = sum_b[qg] = 0.f;
         }
         zero(nxt);
+        st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
         if constexpr (C::STREAM) t_load = st.select(t_load);   // the stream element's own unit and tile index

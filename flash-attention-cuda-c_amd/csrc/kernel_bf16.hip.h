@@ -39,6 +39,8 @@ struct Opt {
     int vpre = 2;                // V^T fragments in flight ahead of their MFMA
     int thr = 8;                 // lazy-rescale threshold of the tracked pass, log2 units
     int r = 1;                   // 32-row query groups per wave: 1 = 8 waves, two per SIMD; 2 = 4 waves (experimental arm)
+    int waves = 0;               // waves per workgroup (0: 8 / r).  4 with r = 1: 128-row units, and where the ring is <= 80 KiB (d = 64) TWO
+                                 // workgroups per CU with independent barriers (the grid is then two workgroups per CU)
     bool asm_mfma = false;       // inline-asm MFMAs with dictated register classes (needed by r = 2)
     int valu_first = -1;         // phase-A slots issue their softmax slice before the MFMA: +2 % on the 32x32x16 engine (it covers the
                                  // fragment's LDS latency), -1 % on the 16x16x32 engine.  -1: on for 32x32x16, off for 16x16x32
@@ -61,6 +63,11 @@ struct Opt {
                                  // than the prologues cost): -3 % non-causal, -4 % causal (profiles/r02_tune_g_unit_streaming.log).  With the
                                  // seam's two iterations peeled out of the loop instead (five inlined copies of the tile step) the register
                                  // allocator spills 1 KB per lane into the loop: -33 % (profiles/r02_tune_h_unit_streaming_peeled.log)
+    bool dma = true;             // K/V tiles global -> LDS by `buffer_load ... lds` (loaders.hip.h: DmaStage): no staging registers (-16 to -20 VGPRs),
+                                 // no ds_write; +2.4 ... +4.5 % on both engines, causal and not (profiles/r02_tune_m_lds_dma.log).  Applies to
+                                 // bf16, unpadded rows, 8 waves (KernelCfg::DMA); padded / fp8 / fp16-weights kernels convert or zero-fill
+                                 // between the load and the LDS write and keep the register path.  The epilogue's LDS regions sit behind ring
+                                 // slot 0: the next unit's tile 0 lands there while the epilogue runs
     bool qk_pair_order = false;  // 32x32x16 engine, bf16: QK^T fragments ordered so that consecutive MFMAs share their Q fragment
     bool p_f16 = false;          // 16x16x32 engine: weights rounded to fp16 (11 significant bits) instead of bf16 (8), V staged as fp16, P.V
                                  // on v_mfma_f32_16x16x32_f16: the precision option behind FA_FLAG_F16_WEIGHTS (needs |V| <= 65504)
@@ -75,9 +82,7 @@ struct Opt {
     bool skip_last_qk = false;   // a wave's last tile step without the (unused) QK^T MFMAs: -1..-2 %
     // ---- TIMING EXPERIMENTS ONLY (wrong results by construction): bit 0 no per-tile barrier, bit 1 no global loads in
     // the tile loop, bit 2 P.V takes a constant P (no VALU -> MFMA dependency), bit 3 every 32x32x16 MFMA replaced by two
-    // 16x16x32 on the same operand registers (same FLOPs, same dataflow shape: what would that MFMA shape cost / save?), bit 4 waves
-    // 4-7 run the P.V phase BEFORE the QK^T phase inside each iteration (the two waves of a SIMD in complementary phases: what would
-    // a half-iteration stagger be worth?) ----
+    // 16x16x32 on the same operand registers (same FLOPs, same dataflow shape: what would that MFMA shape cost / save?) ----
     int dbg = 0;
 };
 
@@ -100,10 +105,13 @@ struct KernelCfg {
     static constexpr bool VALU_FIRST = O.valu_first < 0 ? !M16 : O.valu_first != 0;
     static constexpr bool P_F16 = M16 && O.p_f16;
     static constexpr bool QK_PAIR = O.qk_pair_order && ESZ_ == 2 && !M16;
+    static constexpr bool DMA = O.dma && ESZ_ == 2 && !O.pad && O.r == 1 && O.waves == 0 && O.ring == 3 && !O.p_f16 && O.stream == 0;
     static constexpr bool STREAM = M16 && O.persist && O.optimistic && O.stream != 0;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
-    static constexpr int NWAVES = 8 / O.r;           // waves per workgroup (256 query rows)
+    static constexpr int NWAVES = O.waves > 0 ? O.waves : 8 / O.r;   // waves per workgroup
+    static constexpr int QBLK = 32 * O.r * NWAVES;   // query rows of a unit (256 in production)
+    static_assert(QBLK == 256 || QBLK == 128, "units of 256 or 128 query rows");
     static constexpr int DBG = O.dbg;
     static constexpr bool DBG_NOBAR = DBG & 1, DBG_NOLOAD = DBG & 2, DBG_PCONST = DBG & 4, DBG_M16 = DBG & 8;
     static constexpr int RING = O.ring;
@@ -112,9 +120,11 @@ struct KernelCfg {
     // the fp32 LDS epilogue stages 256 rows x 64 floats: more than the ring at d = 64
     // streamed units: the epilogue's staging regions (per wave 16 rows x D 2-byte outputs, or x 64 floats) sit BEHIND the ring
     static constexpr int EP_WAVE_BYTES = 16 * (sizeof(OutT_) == 2 ? D_ * 2 : 256);
-    static constexpr int EP_BYTES = 8 * EP_WAVE_BYTES;
-    static constexpr int LDS_BYTES = STREAM ? RING_BYTES + EP_BYTES
-                                            : ((O.lds_epilogue32 && sizeof(OutT_) == 4 && RING_BYTES < 65536) ? 65536 : RING_BYTES);
+    static constexpr int EP_BYTES = NWAVES * EP_WAVE_BYTES;
+    // LDS-DMA staging: the epilogue regions (QBLK rows of D 2-byte outputs, or of 64 floats) sit behind ring slot 0
+    static constexpr int EP_OFF = DMA ? TileGeom<D_, ESZ_>::SLOT : 0;
+    static constexpr int EP_NEED = EP_OFF + (sizeof(OutT_) == 2 ? QBLK * D_ * 2 : (O.lds_epilogue32 ? QBLK * 256 : 0));
+    static constexpr int LDS_BYTES = STREAM ? RING_BYTES + EP_BYTES : (EP_NEED > RING_BYTES ? EP_NEED : RING_BYTES);
     static_assert(LDS_BYTES <= 163840 - 256, "160 KiB of LDS per CU, 256 bytes of which __syncthreads_or takes statically");
 };
 
@@ -143,7 +153,7 @@ struct RowSink {
 template <class C, bool TRACK>
 __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>& w, typename WaveComputeOf<C>::Stage& st, lds_ptr smem,
                                                int n_tiles, int my_tiles, int q_row0, int lane,
-                                               unsigned long long (&acc)[12], bool tile0_in_flight, RowSink& sink) {
+                                               unsigned long long (&acc)[15], bool tile0_in_flight, RowSink& sink) {
     using G = TileGeom<C::D, C::ESZ>;
     constexpr bool CAUSAL = C::CAUSAL;
     constexpr int KVBLK = 64, SLOT = G::SLOT, KT = G::K_TILE;
@@ -152,7 +162,8 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
     if constexpr (C::STAMP) tp0 = cycle_stamp();
     w.init();
     using WC = WaveComputeOf<C>;
-    const int kbase = C::M16 ? k16_read_base(lane) : k_read_base(lane);
+    constexpr int KBLK = (G::ROWB / 16) * 128;   // DMA form of the K image: bytes per 8-key block
+    const int kbase = C::DMA ? (C::M16 ? kd16_read_base(lane, KBLK) : kd_read_base(lane, KBLK)) : (C::M16 ? k16_read_base(lane) : k_read_base(lane));
     const int vbase = C::M16 ? v16_read_base<C::D>(lane) : v_read_base(lane);
     const float c = p.scale_log2;
     auto needs_mask = [&](int t) { return (CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > S); };
@@ -160,10 +171,11 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
 
     // Prologue: tile 0 (requested by the caller together with Q on the first pass) -> LDS, barrier; then
     // tile 1 is fetched while S(0) = K(0).Q^T and its row max are computed.
-    if (!tile0_in_flight) st.load_all(0);
+    if (!tile0_in_flight) st.load_all_into(0, smem);
     st.write_all(smem);
+    st.wait_all();
     __syncthreads();
-    st.load_all(1);          // past-the-end tiles read as zeros (buffer range check)
+    st.load_all_into(1, smem + SLOT);          // past-the-end tiles read as zeros (buffer range check)
     constexpr int AHEAD = C::RING - 1;                 // iteration t stages tile t + AHEAD
     u32x4 r2[WC::Stage::NL];                           // 4-slot ring: tile 2 travels with tile 1
     if constexpr (C::RING == 4) st.load_all_to(r2, 2);
@@ -175,6 +187,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
     }
     st.write_all(smem + SLOT);
     if constexpr (C::RING == 4) st.write_all_from(r2, smem + 2 * SLOT);
+    st.wait_all();
     __syncthreads();
     if constexpr (C::RING == 4) w.k_prefetch(smem + SLOT, kbase);   // K(1) fragments of step 0 (later steps: before their barrier)
     if constexpr (C::STAMP) { tp2 = cycle_stamp(); acc[8] += tp1 - tp0; acc[9] += tp2 - tp1; }
@@ -195,7 +208,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
                 w.template tile_step<TRACK, true>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur,
                                                   nxt, false, false, 0, q_row0, S, lane, smem + so_n2);
         } else {
-            st.load_all(t + AHEAD);
+            st.load_all_into(t + AHEAD, smem + so_wr);
             st.write_all(smem + so_wr);
             if constexpr (C::EARLY_STORE && !TRACK) {
                 // This wave is past its causal diagonal: its O and l are final, and it has nothing to do but stage
@@ -211,6 +224,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
             }
         }
         if constexpr (C::STAMP) t4 = cycle_stamp();
+        st.wait_all();   // (LDS-DMA staging: this wave's pieces of tile t + AHEAD have landed)
         if constexpr (C::DBG_NOBAR) {
         } else if constexpr (C::RING == 4) {
             // __syncthreads() would drain lgkmcnt(0) and with it the K fragments just requested for the next
@@ -295,7 +309,7 @@ struct UnitCtx {
     int q_row0, n_tiles, my_tiles;
     bool wave_live;
     __device__ __forceinline__ void set(const Params& p, int g, int qb, int wave) {
-        constexpr int ESZ = C::ESZ, KVBLK = 64, QBLK = 256, WROWS = 32 * C::R;
+        constexpr int ESZ = C::ESZ, KVBLK = 64, QBLK = C::QBLK, WROWS = 32 * C::R;
         const int b = g / p.H, h = g - b * p.H;
         Qh = (const char*)p.Q + (b * p.qB + h * p.qH) * ESZ;
         Kh = (const char*)p.K + (b * p.kB + h * p.kH) * ESZ;
@@ -357,7 +371,7 @@ __device__ __forceinline__ void stream_units16(const Params& p, lds_ptr smem) {
         else w.load_q(u0.Qh, qSb, u0.q_row0, S, lane, row_bytes);
     }
     bool q_as_rows = C::COALESCED_Q;                 // only the workgroup's first unit takes the coalesced form (the ring is empty then)
-    unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     Scores16 sA, sB;
     bool fresh = true;                               // this unit starts with a full prologue
     int so_cur = 0, so_nxt = SLOT, so_wr = 2 * SLOT; // ring slot byte offsets of stream elements t, t+1, t+2
@@ -381,7 +395,7 @@ __device__ __forceinline__ void stream_units16(const Params& p, lds_ptr smem) {
         if (fresh) {
             w.pin_q();
             if (q_as_rows) {
-                static_assert(!C::COALESCED_Q || G::SLOT + 256 * D * ESZ <= C::LDS_BYTES, "Q staging regions must fit behind slot 0");
+                static_assert(!C::COALESCED_Q || G::SLOT + C::QBLK * D * ESZ <= C::LDS_BYTES, "Q staging regions must fit behind slot 0");
                 if constexpr (C::COALESCED_Q) {
                     w.q_rows_to_fragments(smem + G::SLOT + wave * (WROWS * D * ESZ), lane_u);
                     w.pin_q();
@@ -542,10 +556,11 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
     typename WaveComputeOf<C>::Stage st;
     const int row_bytes = C::PAD ? p.d * ESZ : D * ESZ, orow_bytes = C::PAD ? p.d * (int)sizeof(OutT) : D * (int)sizeof(OutT);
     st.init(cur.Kh, cur.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
-    st.load_all(0);                                 // tile 0 and Q travel together (one HBM round trip)
+    st.load_all_into(0, smem);                      // tile 0 and Q travel together (one HBM round trip)
     if constexpr (C::COALESCED_Q) w.load_q_rows(cur.Qh, qSb, cur.q_row0, S, lane);
     else w.load_q(cur.Qh, qSb, cur.q_row0, S, lane, row_bytes);
-    unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (C::STAMP) acc[12] = cycle_stamp() - t_kernel0;   // setup: unit decode, descriptors, first loads issued
 
     while (true) {
         unsigned long long t_q0 = 0;
@@ -556,7 +571,7 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
             // staging regions sit behind ring slot 0 (tile 0 is about to be written there by other waves); every
             // wave finishes this round trip before the first barrier of the pass, after which slot 1 is written
             using G = TileGeom<D, ESZ>;
-            static_assert(G::SLOT + 256 * D * ESZ <= C::LDS_BYTES, "Q staging regions must fit behind slot 0");
+            static_assert(G::SLOT + C::QBLK * D * ESZ <= C::LDS_BYTES, "Q staging regions must fit behind slot 0");
             int lane_q = lane;   // keep the 16 staging addresses inside the unit loop (hoisted, they spill)
             if constexpr (C::PERSIST) asm volatile("" : "+v"(lane_q));
             w.q_rows_to_fragments(smem + G::SLOT + wave * (WROWS * D * ESZ), lane_q);
@@ -582,12 +597,14 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
         // this unit's epilogue (Q's registers and the staging registers are dead once the pass is over).
         bool more = false;
         UnitCtx<C> nxt;
+        unsigned long long t_nx0 = 0;
+        if constexpr (C::STAMP) t_nx0 = cycle_stamp();
         if constexpr (C::PERSIST) {
             more = work_unit<C>(p, ++round, g, qb);
             if (more) {
                 nxt.set(p, g, qb, wave);
                 st.init(nxt.Kh, nxt.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
-                st.load_all(0);
+                st.load_all_into(0, smem);   // (DMA form: straight into ring slot 0 -- the epilogue below works behind it)
                 // (opaque lane: a hoisted per-lane Q address is spilled across the tile loop, and its reload's vmcnt(0)
                 // would make the Q loads wait for the tile-0 loads just issued)
                 int lane_n = lane;
@@ -599,20 +616,20 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
         }
 
         unsigned long long t_ep0 = 0;
-        if constexpr (C::STAMP) t_ep0 = cycle_stamp();
+        if constexpr (C::STAMP) { t_ep0 = cycle_stamp(); acc[13] += t_ep0 - t_nx0; }   // next unit decode + prefetch issue
         // The epilogue's ~40 per-lane addresses must be recomputed here: hoisted out of the unit loop they
         // would live across the tile loop, spill, and their reload (vmcnt(0)) would wait for the prefetch above.
         int lane_e = lane;
         if constexpr (C::PERSIST) asm volatile("" : "+v"(lane_e));
         if constexpr (sizeof(OutT) == 2) {
             // every pass ends behind a workgroup barrier, so no wave still reads the K/V ring: reuse it
-            static_assert(256 * D * 2 <= C::LDS_BYTES, "epilogue regions must fit the ring");
+            static_assert(C::EP_OFF + C::QBLK * D * 2 <= C::LDS_BYTES, "epilogue regions must fit the ring");
             if (cur.wave_live && !sink.stored)
-                w.template store_o_lds<OutT>(smem + wave * (WROWS * D * 2), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e, orow_bytes);
+                w.template store_o_lds<OutT>(smem + C::EP_OFF + wave * (WROWS * D * 2), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e, orow_bytes);
         } else if constexpr (C::LDS_EPILOGUE32) {
-            static_assert(256 * 64 * 4 <= C::LDS_BYTES, "epilogue regions must fit the ring");
+            static_assert(C::EP_OFF + C::QBLK * 64 * 4 <= C::LDS_BYTES, "epilogue regions must fit the ring");
             if (cur.wave_live && !sink.stored)
-                w.template store_o_lds32<OutT>(smem + wave * (WROWS * 256), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e, orow_bytes);
+                w.template store_o_lds32<OutT>(smem + C::EP_OFF + wave * (WROWS * 256), cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e, orow_bytes);
         } else {
             if (cur.wave_live && !sink.stored) w.template store_o<OutT>(cur.Oh, cur.lse_head, oSb, cur.q_row0, S, lane_e, orow_bytes);
         }
@@ -623,12 +640,17 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
         cur = nxt;
     }
     if constexpr (C::STAMP) {
+        const unsigned long long t_tail0 = cycle_stamp();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the store tail
-        acc[0] = cycle_stamp() - t_kernel0;                // whole workgroup lifetime of this wave
+        const unsigned long long t_end = cycle_stamp();
+        acc[14] = t_end - t_tail0;
+        acc[0] = t_end - t_kernel0;                        // whole workgroup lifetime of this wave
         if (lane == 0 && p.dbg) {
 #pragma unroll
             for (int k = 0; k < 11; ++k) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + k] = acc[k];
             p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 11] = 1;   // (rows of waves that do not exist stay 0)
+#pragma unroll
+            for (int k = 12; k < 15; ++k) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + k] = acc[k];
         }
     }
 }

@@ -81,6 +81,12 @@ struct TileGeom {
     __host__ __device__ static constexpr int v16_lds_off(int key, int chunk) {
         return (key >> 3) * (DG * 256) + (chunk >> 1) * 256 + (key & 7) * 32 + (chunk & 1) * 16;
     }
+    // K image of the LDS-DMA staging (DmaStage below): [key/8][chunk slot][key%8][16 B]; with kxor (32x32x16 engine) slot c' of an odd
+    // 8-key block holds chunk c' ^ 1
+    static constexpr int KBLK = (ROWB / 16) * 128;
+    __host__ __device__ static constexpr int kd_lds_off(int key, int chunk, bool kxor) {
+        return (key >> 3) * KBLK + (chunk ^ (kxor ? (key >> 3) & 1 : 0)) * 128 + (key & 7) * 16;
+    }
 };
 
 // Per-lane LDS read bases (everything else is an immediate offset).
@@ -234,6 +240,93 @@ struct BufStage {
     template <int N = 0> __device__ __forceinline__ void write_all_from(const u32x4 (&src)[NL], lds_ptr s) const { if constexpr (N < NW) { write_from<N>(src, s); write_all_from<N + 1>(src, s); } }
     template <int N = 0> __device__ __forceinline__ void load_all(int t) { if constexpr (N < NL) { load<N>(t); load_all<N + 1>(t); } }
     template <int N = 0> __device__ __forceinline__ void write_all(lds_ptr s) const { if constexpr (N < NW) { write<N>(s); write_all<N + 1>(s); } }
+    // (interface shared with DmaStage, whose loads need their LDS destination)
+    __device__ __forceinline__ void set_dst(lds_ptr) {}
+    __device__ __forceinline__ void load_all_into(int t, lds_ptr) { load_all(t); }
+    __device__ __forceinline__ void wait_all() const {}
+};
+
+// ---- LDS-DMA staging (Opt::dma; bf16, unpadded rows, 8 waves) -------------------------------------------------------------
+// K/V tiles go global -> LDS by `buffer_load_dwordx4 ... lds`: no staging registers, no ds_write.  One wave-instruction writes 1 KiB
+// of LDS linearly (lane l -> M0 base + 16 l) from per-lane SOURCE addresses, so the images must be cut into 1-KiB pieces whose lane
+// order still reads whole 128-byte lines of global memory:
+//   K image (DMA form):  [key/8][16-byte chunk c'][key%8][16 B]  (8-key block = ROWB/16 chunks x 128 B), where slot c' of a block
+//       holds chunk c' ^ (block & 1) for the 32x32x16 engine (KXOR) and chunk c' for the 16x16x32 engine: with that, the 16-lane groups
+//       of both engines' ds_read_b128 fragment reads cover all 64 banks (kd_read_base / kd16_read_base; immediates only, as before).
+//       Piece (g, j) = chunks 8j .. 8j+7 of key group g: lane l <- key 8g + (l&7), chunk 8j + ((l>>3) ^ parity) -- the same lane order as
+//       the register path's K loads (8 lines of 128 B per instruction, each fully used).
+//   V images unchanged (both are made of 512-byte / 256-byte subtiles that are contiguous per 8 keys):
+//       32x32x16 image: piece (g, j) = d-blocks 2j, 2j+1 of key group g: lane l <- key 8g + ((l>>2)&7), chunk 8j + 4(l>>5) + (l&3)
+//       16x16x32 image: piece (g, j) = d-groups 4j .. 4j+3:              lane l <- key 8g + ((l>>1)&7), chunk 8j + 2(l>>4) + (l&1)
+// Rows past the head's extent fail the buffer range check and arrive as zeros, as on the register path.
+__device__ __forceinline__ int kd_read_base(int lane, int blk_bytes) {    // 32x32x16 engine: + kt*(4*blk) + u*256
+    const int r = lane & 31, h = lane >> 5;
+    return (r >> 3) * blk_bytes + ((h ^ ((r >> 3) & 1)) * 128) + (r & 7) * 16;
+}
+__device__ __forceinline__ int kd16_read_base(int lane, int blk_bytes) {  // 16x16x32 engine: + kg*(2*blk) + ks*512
+    const int r = lane & 15, h4 = lane >> 4;
+    return (r >> 3) * blk_bytes + h4 * 128 + (r & 7) * 16;
+}
+template <int D, int NWAVES, bool V16, bool KXOR>
+struct DmaStage {
+    using G = TileGeom<D, 2>;
+    static constexpr int HALVES = G::ROWB / 128;
+    static constexpr int GPW = 8 / NWAVES;
+    static_assert(GPW == 1, "DMA staging: 8 waves, one 8-key group each");
+    static constexpr int LOADS = HALVES;                          // 1-KiB pieces per wave per tensor per tile
+    static constexpr int NL = 2 * LOADS, NW = 0;
+    static constexpr int KBLK = (G::ROWB / 16) * 128;             // bytes of one 8-key block of the K image
+    static constexpr int VBLK = V16 ? G::DG * 256 : G::DB * 512;  // ... of the V image
+    u32x4 krsrc, vrsrc;    // raw buffer descriptors (stride 0; word 3 as __builtin_amdgcn_make_buffer_rsrc(..., 0x00020000))
+    int koff, voff;        // per-lane source byte offset of piece 0 inside a tile
+    int ktile, vtile;      // bytes per 64-key tile step (scalar)
+    int kdst, vdst;        // this wave's block inside the K / V image (scalar)
+    uint32_t dst;          // LDS byte address of the ring slot the next loads go to (scalar)
+    __device__ __forceinline__ static u32x4 descriptor(const char* base, int bytes) {
+        const uint64_t a = (uint64_t)base;
+        return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)bytes, 0x00020000u};
+    }
+    __device__ __forceinline__ void init(const char* Kh, const char* Vh, int64_t kS_bytes, int64_t vS_bytes, int S, int wave, int lane,
+                                         int row_bytes = D * 2) {
+        krsrc = descriptor(Kh, (int)((S - 1) * kS_bytes + row_bytes));
+        vrsrc = descriptor(Vh, (int)((S - 1) * vS_bytes + row_bytes));
+        ktile = (int)(64 * kS_bytes);
+        vtile = (int)(64 * vS_bytes);
+        const int g = wave;
+        koff = (8 * g + (lane & 7)) * (int)kS_bytes + ((lane >> 3) ^ (KXOR ? (g & 1) : 0)) * 16;
+        voff = V16 ? (8 * g + ((lane >> 1) & 7)) * (int)vS_bytes + (2 * (lane >> 4) + (lane & 1)) * 16
+                   : (8 * g + ((lane >> 2) & 7)) * (int)vS_bytes + (4 * (lane >> 5) + (lane & 3)) * 16;
+        kdst = g * KBLK;
+        vdst = G::K_TILE + g * VBLK;
+    }
+    __device__ __forceinline__ void set_dst(lds_ptr slot) { dst = (uint32_t)(uintptr_t)slot; }
+    // The DMA is issued from inline asm: hipcc then keeps no account of it -- issued through the builtin, every ds_read_b64_tr_b16 that
+    // follows waits vmcnt(0) for it (the V^T reads of the SAME iteration), because the waitcnt pass cannot tell the ring slots apart.
+    // Ordering is by hand instead: wait_all() before the barrier that publishes the tile.  M0 (the LDS destination) is written in the
+    // statement that uses it and restored.  The instruction offset stays 0 (it would be added to the LDS address as well); the tile
+    // offset goes into the VGPR offset so that the range check covers it.
+    __device__ __forceinline__ static void dma16(const u32x4& rsrc, uint32_t lds_byte, int voffset) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voffset), "s"(rsrc), "s"(lds_byte)
+                     : "memory");
+    }
+    // piece #N of tile t (N < LOADS: K, else V) -> ring slot `dst`
+    template <int N>
+    __device__ __forceinline__ void load(int t) const {
+        constexpr int j = N < LOADS ? N : N - LOADS;
+        if constexpr (N < LOADS) dma16(krsrc, dst + kdst + j * 1024, koff + t * ktile + j * 128);
+        else dma16(vrsrc, dst + vdst + j * 1024, voff + t * vtile + j * 128);
+    }
+    // every piece this wave has issued has landed in LDS (then a barrier publishes it to the other waves)
+    __device__ __forceinline__ void wait_all() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    template <int N>
+    __device__ __forceinline__ void write(lds_ptr) const {}
+    __device__ __forceinline__ void pin_all() {}
+    template <int N = 0> __device__ __forceinline__ void load_all(int t) const { if constexpr (N < NL) { load<N>(t); load_all<N + 1>(t); } }
+    __device__ __forceinline__ void load_all_into(int t, lds_ptr slot) { set_dst(slot); load_all(t); }
+    __device__ __forceinline__ void write_all(lds_ptr) const {}
 };
 
 }  // namespace fa

@@ -63,7 +63,13 @@ static void launch_cfg(const Params& p, int grid) {
     if constexpr (K::PERSIST) {
         // one workgroup per CU (256 on MI355X), or one per unit when there are fewer units than CUs
         Params q = p;
-        q.jpx = std::min(p.cpx, g_jpx > 0 ? g_jpx : g_cus / 8);
+        if constexpr (K::QBLK != 256) {   // 128-row units: twice the units, and (ring permitting) two workgroups per CU
+            q.nQ = (p.S + K::QBLK - 1) / K::QBLK;
+            q.units = p.B * p.H * q.nQ;
+            q.cpx = (q.units + 7) / 8;
+        }
+        const int wg_per_cu = (K::QBLK == 128 && 2 * (K::LDS_BYTES + 512) <= 163840) ? 2 : 1;
+        q.jpx = std::min(q.cpx, g_jpx > 0 ? g_jpx : wg_per_cu * g_cus / 8);
         hipLaunchKernelGGL((fwd_mfma_kernel<K>), dim3(8 * q.jpx), dim3(64 * K::NWAVES), K::LDS_BYTES, nullptr, q);
     } else {
         hipLaunchKernelGGL((fwd_mfma_kernel<K>), dim3(grid), dim3(64 * K::NWAVES), K::LDS_BYTES, nullptr, p);
@@ -77,19 +83,25 @@ static std::vector<Variant> make_variants() {
     std::vector<Variant> v;
     v.push_back({"production (16x16x32 non-causal, 32x32x16 causal)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
     v.push_back({"16x16x32 MFMAs", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1}>>});
+    v.push_back({"32x32x16 MFMAs", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0}>>});
+    v.push_back({"register staging (no LDS-DMA), 16x16x32", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1, .dma = false}>>});
+    v.push_back({"register staging (no LDS-DMA), 32x32x16", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0, .dma = false}>>});
 #ifdef FA_TUNE_SWEEP
-    v.push_back({"npre 6", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6}>>});
-    v.push_back({"npre 8", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 8}>>});
-    v.push_back({"vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3}>>});
-    v.push_back({"vpre 4", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 4}>>});
-    v.push_back({"npre 6 vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3}>>});
-    v.push_back({"npre 2 vpre 1", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 2, .vpre = 1}>>});
-    v.push_back({"VALU-first slots", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = 1}>>});
+    v.push_back({"npre 6", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .m16 = CAUSAL ? 0 : -1}>>});
+    v.push_back({"npre 8", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 8, .m16 = CAUSAL ? 0 : -1}>>});
+    v.push_back({"vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .m16 = CAUSAL ? 0 : -1}>>});
+    v.push_back({"vpre 4", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 4, .m16 = CAUSAL ? 0 : -1}>>});
+    v.push_back({"npre 6 vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3, .m16 = CAUSAL ? 0 : -1}>>});
+    v.push_back({"npre 2 vpre 1", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 2, .vpre = 1, .m16 = CAUSAL ? 0 : -1}>>});
+    v.push_back({"slot order flipped (VALU-first <-> MFMA-first)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = CAUSAL ? 0 : 1, .m16 = CAUSAL ? 0 : -1}>>});
 #endif
+    if constexpr (D == 64) {
+        v.push_back({"4 waves x 32 rows: 128-row units, two workgroups per CU", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.waves = 4, .m16 = CAUSAL ? 0 : -1}>>});
+        v.push_back({"4 waves x 32 rows, the other engine", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.waves = 4, .m16 = CAUSAL ? 1 : 0}>>});
+    }
     v.push_back({"unit streaming (no per-unit prologue)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.stream = 1}>>});
     v.push_back({"fp16 weights (FA_FLAG_F16_WEIGHTS)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>});
     v.push_back({"exact row sums (the LSE instantiation)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.sum_mfma = 0}>>});
-    v.push_back({"32x32x16 MFMAs (round-1 production)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0}>>});
 #ifdef FA_TUNE_FULL   // the round-1 arms (rejected by measurement): ~3 more minutes of compile time
     v.push_back({"waits grouped by 2 (npre4 vpre3)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .wg = 2}>>});
     v.push_back({"waits grouped by 2 (npre6 vpre3)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3, .wg = 2}>>});
@@ -260,8 +272,18 @@ int main(int argc, char** argv) {
     for (size_t vi = 0; vi < vars.size(); ++vi) { vars[vi].launch(p, grid); vars[vi].launch(p, grid); }
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemset(ddbg, 0, (size_t)grid * 128 * 8));   // stamp rows: only the STAMP variant(s) timed below write them
-    for (int r = 0; r < rounds; ++r)
-        for (size_t vi = 0; vi < vars.size(); ++vi) {
+    // every round visits the variants in a fresh (seeded) random order: a variant's clock depends on what ran just before it
+    // (a fixed order gave identical kernels 3.6 % apart), so the predecessor must not be the same in every round
+    std::vector<size_t> order(vars.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    unsigned long long lcg = 0x9E3779B97F4A7C15ull;
+    for (int r = 0; r < rounds; ++r) {
+        for (size_t i = order.size(); i > 1; --i) {
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(order[i - 1], order[(lcg >> 33) % i]);
+        }
+        for (size_t oi = 0; oi < order.size(); ++oi) {
+            const size_t vi = order[oi];
             HIP_CHECK(hipEventRecord(e0, nullptr));
             for (int i = 0; i < reps; ++i) vars[vi].launch(p, grid);
             HIP_CHECK(hipEventRecord(e1, nullptr));
@@ -270,12 +292,13 @@ int main(int argc, char** argv) {
             HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
             ms[vi].push_back(t / reps);
         }
+    }
     {   // segment stamps of the STAMP variant (if it ran)
         std::vector<unsigned long long> h((size_t)grid * 128);
         HIP_CHECK(hipMemcpy(h.data(), ddbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double seg[12] = {0};
+        double seg[15] = {0};
         for (size_t i = 0; i < (size_t)grid * 8; ++i)
-            for (int k = 0; k < 12; ++k) seg[k] += (double)h[i * 16 + k];
+            for (int k = 0; k < 15; ++k) seg[k] += (double)h[i * 16 + k];
         if (seg[6] > 0) {
             const double nt = seg[6], nw = seg[11] > 0 ? seg[11] : 1;
             printf("  STAMP build (each stamp costs ~40-60 cycles):\n");
@@ -308,6 +331,8 @@ int main(int argc, char** argv) {
             printf("    per workgroup-wave (%.0f waves): lifetime %.0f = Q load+pin %.0f | stage tiles 0,1 + barrier %.0f | QK(0)+max %.0f | tile loop %.0f (%.1f%%) | finite check %.0f | epilogue %.0f | unaccounted %.0f\n",
                    nw, tot, seg[7] / nw, seg[8] / nw, seg[9] / nw, loop, 100 * loop / tot, seg[10] / nw, seg[4] / nw,
                    tot - loop - (seg[7] + seg[8] + seg[9] + seg[10] + seg[4]) / nw);
+            printf("      of the unaccounted: setup (unit decode, descriptors, first loads issued) %.0f | next unit decode + prefetch issue %.0f | store tail (vmcnt(0) at exit) %.0f\n",
+                   seg[12] / nw, seg[13] / nw, seg[14] / nw);
         }
     }
     const double flops = (causal ? 2.0 : 4.0) * BH * (double)S * S * d;

@@ -240,10 +240,11 @@ static void test_mfma_layouts() {
 }
 
 // ------------------------------------------------------------------------------------------------ (2) LDS images
-template <int D>
+template <int D, bool DMA>
 __global__ __launch_bounds__(512) void lds_image_kernel(const uint16_t* K, const uint16_t* V, int S, uint16_t* img, uint16_t* kfr,
                                                         uint16_t* vfr) {
-    using C = KernelCfg<D, false, __bf16, 2, Opt{.m16 = 0}>;   // the 32x32x16 engine (what the fp8 kernels run)
+    using C = KernelCfg<D, false, __bf16, 2, Opt{.m16 = 0, .dma = DMA}>;   // the 32x32x16 engine; DMA: LDS-DMA staging (production)
+    static_assert(C::DMA == DMA);
     using G = TileGeom<D, 2>;
     using W = WaveCompute<C>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -251,13 +252,14 @@ __global__ __launch_bounds__(512) void lds_image_kernel(const uint16_t* K, const
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     typename W::Stage st;
     st.init((const char*)K, (const char*)V, D * 2, D * 2, S, wave, lane);
-    st.load_all(0);
+    st.load_all_into(0, smem);
     st.write_all(smem);
+    st.wait_all();
     __syncthreads();
     for (int i = threadIdx.x; i < G::SLOT / 2; i += blockDim.x) img[i] = *reinterpret_cast<FA_LDS uint16_t*>(smem + 2 * i);
     if (wave == 0) {
         W w;
-        const int kbase = k_read_base(lane), vbase = v_read_base(lane);
+        const int kbase = DMA ? kd_read_base(lane, G::KBLK) : k_read_base(lane), vbase = v_read_base(lane);
         for (int f = 0; f < W::NF; ++f) {
             const u32x4 kf = w.k_read(smem, kbase, f);
             for (int e = 0; e < 4; ++e) { kfr[(f * 64 + lane) * 8 + 2 * e] = kf[e] & 0xffff; kfr[(f * 64 + lane) * 8 + 2 * e + 1] = kf[e] >> 16; }
@@ -269,10 +271,10 @@ __global__ __launch_bounds__(512) void lds_image_kernel(const uint16_t* K, const
     }
 }
 
-template <int D>
+template <int D, bool DMA>
 static void test_lds_image() {
     using G = TileGeom<D, 2>;
-    using W = WaveCompute<KernelCfg<D, false, __bf16, 2, Opt{.m16 = 0}>>;
+    using W = WaveCompute<KernelCfg<D, false, __bf16, 2, Opt{.m16 = 0, .dma = DMA}>>;
     constexpr int S = 64;
     std::vector<uint16_t> hk(S * D), hv(S * D);
     for (int i = 0; i < S * D; ++i) { hk[i] = (uint16_t)(i + 1); hv[i] = (uint16_t)(0x8000 + i + 1); }   // "i + 1", V tagged
@@ -282,23 +284,24 @@ static void test_lds_image() {
     HIP_CHECK(hipMemcpy(dk, hk.data(), S * D * 2, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dv, hv.data(), S * D * 2, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemset(dimg, 0, G::SLOT));
-    HIP_CHECK(hipFuncSetAttribute((const void*)lds_image_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G::SLOT));
-    hipLaunchKernelGGL(lds_image_kernel<D>, dim3(1), dim3(512), 3 * G::SLOT, nullptr, dk, dv, S, dimg, dkf, dvf);
+    HIP_CHECK(hipFuncSetAttribute((const void*)lds_image_kernel<D, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G::SLOT));
+    hipLaunchKernelGGL((lds_image_kernel<D, DMA>), dim3(1), dim3(512), 3 * G::SLOT, nullptr, dk, dv, S, dimg, dkf, dvf);
     HIP_CHECK(hipDeviceSynchronize());
     std::vector<uint16_t> img(G::SLOT / 2), kf(W::NF * 64 * 8), vf(W::NB * 64 * 8);
     HIP_CHECK(hipMemcpy(img.data(), dimg, G::SLOT, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(kf.data(), dkf, kf.size() * 2, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(vf.data(), dvf, vf.size() * 2, hipMemcpyDeviceToHost));
-    char name[160];
+    char name[220];
     // raw image == the documented permutation of the i + 1 tile
     long long bad = 0;
     for (int key = 0; key < 64; ++key)
         for (int ch = 0; ch < D / 8; ++ch)
             for (int e = 0; e < 8; ++e) {
-                bad += img[G::k_lds_off(key, ch) / 2 + e] != hk[key * D + 8 * ch + e];
+                bad += img[(DMA ? G::kd_lds_off(key, ch, true) : G::k_lds_off(key, ch)) / 2 + e] != hk[key * D + 8 * ch + e];
                 bad += img[(G::K_TILE + G::v_lds_off(key, ch)) / 2 + e] != hv[key * D + 8 * ch + e];
             }
-    snprintf(name, sizeof name, "lds image d=%d: K chunk-major + V [key/8][d/32][key%%8][d%%32] == permutation of the i+1 tile", D);
+    snprintf(name, sizeof name, "lds image d=%d%s: K %s + V [key/8][d/32][key%%8][d%%32] == permutation of the i+1 tile", D,
+             DMA ? " (LDS-DMA)" : "", DMA ? "[key/8][chunk^blk][key%8]" : "chunk-major");
     report(name, bad, 2LL * 64 * D);
     // K fragment f = (32-key half kt = f / FPH, k-step u = f % FPH): lane (r, h), element j = K[32kt + r][16u + 8h + j]
     bad = 0;
@@ -308,7 +311,7 @@ static void test_lds_image() {
                 const int kt = f / W::FPH, u = f % W::FPH, r = lane & 31, h = lane >> 5;
                 bad += kf[(f * 64 + lane) * 8 + j] != hk[(32 * kt + r) * D + 16 * u + 8 * h + j];
             }
-    snprintf(name, sizeof name, "lds image d=%d: K A-fragments (ds_read_b128) hold K[32kt+r][16u+8h+j]", D);
+    snprintf(name, sizeof name, "lds image d=%d%s: K A-fragments (ds_read_b128) hold K[32kt+r][16u+8h+j]", D, DMA ? " (LDS-DMA)" : "");
     report(name, bad, (long long)W::NF * 64 * 8);
     // V^T fragment v = (16-key step s4 = v / DB, d block db = v % DB): lane (r, h), element j = V[16s4 + 8(j>>2) + 4h + (j&3)][32db + r]
     bad = 0;
@@ -319,7 +322,7 @@ static void test_lds_image() {
                 const int key = 16 * s4 + 8 * (j >> 2) + 4 * h + (j & 3);
                 bad += vf[(v * 64 + lane) * 8 + j] != hv[key * D + 32 * db + r];
             }
-    snprintf(name, sizeof name, "lds image d=%d: V^T A-fragments (ds_read_b64_tr_b16) hold V[16s4+8(j>>2)+4h+(j&3)][32db+r]", D);
+    snprintf(name, sizeof name, "lds image d=%d%s: V^T A-fragments (ds_read_b64_tr_b16) hold V[16s4+8(j>>2)+4h+(j&3)][32db+r]", D, DMA ? " (LDS-DMA)" : "");
     report(name, bad, (long long)W::NB * 64 * 8);
     HIP_CHECK(hipFree(dk)); HIP_CHECK(hipFree(dv)); HIP_CHECK(hipFree(dimg)); HIP_CHECK(hipFree(dkf)); HIP_CHECK(hipFree(dvf));
 }
@@ -327,11 +330,11 @@ static void test_lds_image() {
 // The same for the 16x16x32 engine (computers16.hip.h): V image [key/8][d/16][key%8][d%16]; K fragment f = (key group kg = f / KS,
 // k-step ks = f % KS): lane (r = l&15, h4 = l>>4), element j = K[16kg + r][32ks + 8h4 + j]; V^T fragment v = (k-step kk = v / DG,
 // d group dg = v % DG): element j = V[32kk + 16(j>>2) + 4h4 + (j&3)][16dg + r].
-template <int D>
+template <int D, bool DMA>
 __global__ __launch_bounds__(512) void lds_image16_kernel(const uint16_t* K, const uint16_t* V, int S, uint16_t* img, uint16_t* kfr,
                                                           uint16_t* vfr) {
-    using C = ProdCfg<D, false, __bf16>;
-    static_assert(C::M16, "production bf16 configuration runs the 16x16x32 engine");
+    using C = KernelCfg<D, false, __bf16, 2, Opt{.m16 = 1, .dma = DMA}>;
+    static_assert(C::M16 && C::DMA == DMA);
     using G = TileGeom<D, 2>;
     using W = WaveCompute16<C>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -339,13 +342,14 @@ __global__ __launch_bounds__(512) void lds_image16_kernel(const uint16_t* K, con
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     typename W::Stage st;
     st.init((const char*)K, (const char*)V, D * 2, D * 2, S, wave, lane);
-    st.load_all(0);
+    st.load_all_into(0, smem);
     st.write_all(smem);
+    st.wait_all();
     __syncthreads();
     for (int i = threadIdx.x; i < G::SLOT / 2; i += blockDim.x) img[i] = *reinterpret_cast<FA_LDS uint16_t*>(smem + 2 * i);
     if (wave == 0) {
         W w;
-        const int kbase = k16_read_base(lane), vbase = v16_read_base<D>(lane);
+        const int kbase = DMA ? kd16_read_base(lane, G::KBLK) : k16_read_base(lane), vbase = v16_read_base<D>(lane);
         for (int f = 0; f < W::NF; ++f) {
             const u32x4 kf = w.k_read(smem, kbase, f);
             for (int e = 0; e < 4; ++e) { kfr[(f * 64 + lane) * 8 + 2 * e] = kf[e] & 0xffff; kfr[(f * 64 + lane) * 8 + 2 * e + 1] = kf[e] >> 16; }
@@ -357,10 +361,10 @@ __global__ __launch_bounds__(512) void lds_image16_kernel(const uint16_t* K, con
     }
 }
 
-template <int D>
+template <int D, bool DMA>
 static void test_lds_image16() {
     using G = TileGeom<D, 2>;
-    using W = WaveCompute16<ProdCfg<D, false, __bf16>>;
+    using W = WaveCompute16<KernelCfg<D, false, __bf16, 2, Opt{.m16 = 1, .dma = DMA}>>;
     constexpr int S = 64;
     std::vector<uint16_t> hk(S * D), hv(S * D);
     for (int i = 0; i < S * D; ++i) { hk[i] = (uint16_t)(i + 1); hv[i] = (uint16_t)(0x8000 + i + 1); }
@@ -370,22 +374,23 @@ static void test_lds_image16() {
     HIP_CHECK(hipMemcpy(dk, hk.data(), S * D * 2, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dv, hv.data(), S * D * 2, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemset(dimg, 0, G::SLOT));
-    HIP_CHECK(hipFuncSetAttribute((const void*)lds_image16_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G::SLOT));
-    hipLaunchKernelGGL(lds_image16_kernel<D>, dim3(1), dim3(512), 3 * G::SLOT, nullptr, dk, dv, S, dimg, dkf, dvf);
+    HIP_CHECK(hipFuncSetAttribute((const void*)lds_image16_kernel<D, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G::SLOT));
+    hipLaunchKernelGGL((lds_image16_kernel<D, DMA>), dim3(1), dim3(512), 3 * G::SLOT, nullptr, dk, dv, S, dimg, dkf, dvf);
     HIP_CHECK(hipDeviceSynchronize());
     std::vector<uint16_t> img(G::SLOT / 2), kf(W::NF * 64 * 8), vf(W::NV * 64 * 8);
     HIP_CHECK(hipMemcpy(img.data(), dimg, G::SLOT, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(kf.data(), dkf, kf.size() * 2, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(vf.data(), dvf, vf.size() * 2, hipMemcpyDeviceToHost));
-    char name[200];
+    char name[240];
     long long bad = 0;
     for (int key = 0; key < 64; ++key)
         for (int ch = 0; ch < D / 8; ++ch)
             for (int e = 0; e < 8; ++e) {
-                bad += img[G::k_lds_off(key, ch) / 2 + e] != hk[key * D + 8 * ch + e];
+                bad += img[(DMA ? G::kd_lds_off(key, ch, false) : G::k_lds_off(key, ch)) / 2 + e] != hk[key * D + 8 * ch + e];
                 bad += img[(G::K_TILE + G::v16_lds_off(key, ch)) / 2 + e] != hv[key * D + 8 * ch + e];
             }
-    snprintf(name, sizeof name, "lds image (16x16x32 engine) d=%d: K chunk-major + V [key/8][d/16][key%%8][d%%16] == permutation of the i+1 tile", D);
+    snprintf(name, sizeof name, "lds image (16x16x32 engine) d=%d%s: K %s + V [key/8][d/16][key%%8][d%%16] == permutation of the i+1 tile", D,
+             DMA ? " (LDS-DMA)" : "", DMA ? "[key/8][chunk][key%8]" : "chunk-major");
     report(name, bad, 2LL * 64 * D);
     bad = 0;
     for (int f = 0; f < W::NF; ++f)
@@ -394,7 +399,7 @@ static void test_lds_image16() {
                 const int kg = f / W::KS, ks = f % W::KS, r = lane & 15, h4 = lane >> 4;
                 bad += kf[(f * 64 + lane) * 8 + j] != hk[(16 * kg + r) * D + 32 * ks + 8 * h4 + j];
             }
-    snprintf(name, sizeof name, "lds image (16x16x32 engine) d=%d: K A-fragments hold K[16kg+r][32ks+8h4+j]", D);
+    snprintf(name, sizeof name, "lds image (16x16x32 engine) d=%d%s: K A-fragments hold K[16kg+r][32ks+8h4+j]", D, DMA ? " (LDS-DMA)" : "");
     report(name, bad, (long long)W::NF * 64 * 8);
     bad = 0;
     for (int v = 0; v < W::NV; ++v)
@@ -404,7 +409,7 @@ static void test_lds_image16() {
                 const int key = 32 * kk + 16 * (j >> 2) + 4 * h4 + (j & 3);
                 bad += vf[(v * 64 + lane) * 8 + j] != hv[key * D + 16 * dg + r];
             }
-    snprintf(name, sizeof name, "lds image (16x16x32 engine) d=%d: V^T A-fragments hold V[32kk+16(j>>2)+4h4+(j&3)][16dg+r]", D);
+    snprintf(name, sizeof name, "lds image (16x16x32 engine) d=%d%s: V^T A-fragments hold V[32kk+16(j>>2)+4h4+(j&3)][16dg+r]", D, DMA ? " (LDS-DMA)" : "");
     report(name, bad, (long long)W::NV * 64 * 8);
     HIP_CHECK(hipFree(dk)); HIP_CHECK(hipFree(dv)); HIP_CHECK(hipFree(dimg)); HIP_CHECK(hipFree(dkf)); HIP_CHECK(hipFree(dvf));
 }
@@ -521,10 +526,14 @@ static void measure_fp8_accumulation() {
 
 int main() {
     test_mfma_layouts();
-    test_lds_image<128>();
-    test_lds_image<64>();
-    test_lds_image16<128>();
-    test_lds_image16<64>();
+    test_lds_image<128, false>();
+    test_lds_image<64, false>();
+    test_lds_image16<128, false>();
+    test_lds_image16<64, false>();
+    test_lds_image<128, true>();     // the LDS-DMA form of both engines' images (production staging for bf16)
+    test_lds_image<64, true>();
+    test_lds_image16<128, true>();
+    test_lds_image16<64, true>();
     measure_fp8_accumulation();
     printf("%d test(s) failed\n", g_fail);
     return g_fail;
