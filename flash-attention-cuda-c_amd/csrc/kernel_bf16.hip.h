@@ -105,7 +105,7 @@ struct KernelCfg {
     static constexpr bool VALU_FIRST = O.valu_first < 0 ? !M16 : O.valu_first != 0;
     static constexpr bool P_F16 = M16 && O.p_f16;
     static constexpr bool QK_PAIR = O.qk_pair_order && ESZ_ == 2 && !M16;
-    static constexpr bool DMA = O.dma && ESZ_ == 2 && !O.pad && O.r == 1 && O.waves == 0 && O.ring == 3 && !O.p_f16 && O.stream == 0;
+    static constexpr bool DMA = O.dma && ESZ_ == 2 && !O.pad && O.r == 1 && O.ring == 3 && !O.p_f16 && O.stream == 0;
     static constexpr bool STREAM = M16 && O.persist && O.optimistic && O.stream != 0;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)

@@ -271,16 +271,17 @@ template <int D, int NWAVES, bool V16, bool KXOR>
 struct DmaStage {
     using G = TileGeom<D, 2>;
     static constexpr int HALVES = G::ROWB / 128;
-    static constexpr int GPW = 8 / NWAVES;
-    static_assert(GPW == 1, "DMA staging: 8 waves, one 8-key group each");
-    static constexpr int LOADS = HALVES;                          // 1-KiB pieces per wave per tensor per tile
+    static constexpr int GPW = 8 / NWAVES;                        // 8-key groups per wave (8 waves: 1; 4 waves: 2)
+    static_assert(GPW == 1 || GPW == 2, "DMA staging: 8 or 4 waves");
+    static constexpr int LOADS = HALVES * GPW;                    // 1-KiB pieces per wave per tensor per tile
     static constexpr int NL = 2 * LOADS, NW = 0;
-    static constexpr int KBLK = (G::ROWB / 16) * 128;             // bytes of one 8-key block of the K image
+    static constexpr int KBLK = G::KBLK;                          // bytes of one 8-key block of the K image
     static constexpr int VBLK = V16 ? G::DG * 256 : G::DB * 512;  // ... of the V image
     u32x4 krsrc, vrsrc;    // raw buffer descriptors (stride 0; word 3 as __builtin_amdgcn_make_buffer_rsrc(..., 0x00020000))
-    int koff, voff;        // per-lane source byte offset of piece 0 inside a tile
+    int koff[GPW], voff;   // per-lane source byte offset of piece 0 of key group gi inside a tile (K: the slot XOR depends on the group's parity)
     int ktile, vtile;      // bytes per 64-key tile step (scalar)
-    int kdst, vdst;        // this wave's block inside the K / V image (scalar)
+    int kgrp, vgrp;        // bytes per 8-key group step in global memory (scalar)
+    int kdst, vdst;        // this wave's first block inside the K / V image (scalar)
     uint32_t dst;          // LDS byte address of the ring slot the next loads go to (scalar)
     __device__ __forceinline__ static u32x4 descriptor(const char* base, int bytes) {
         const uint64_t a = (uint64_t)base;
@@ -292,12 +293,16 @@ struct DmaStage {
         vrsrc = descriptor(Vh, (int)((S - 1) * vS_bytes + row_bytes));
         ktile = (int)(64 * kS_bytes);
         vtile = (int)(64 * vS_bytes);
-        const int g = wave;
-        koff = (8 * g + (lane & 7)) * (int)kS_bytes + ((lane >> 3) ^ (KXOR ? (g & 1) : 0)) * 16;
-        voff = V16 ? (8 * g + ((lane >> 1) & 7)) * (int)vS_bytes + (2 * (lane >> 4) + (lane & 1)) * 16
-                   : (8 * g + ((lane >> 2) & 7)) * (int)vS_bytes + (4 * (lane >> 5) + (lane & 3)) * 16;
-        kdst = g * KBLK;
-        vdst = G::K_TILE + g * VBLK;
+        kgrp = (int)(8 * kS_bytes);
+        vgrp = (int)(8 * vS_bytes);
+        const int g0 = wave * GPW;
+#pragma unroll
+        for (int gi = 0; gi < GPW; ++gi)
+            koff[gi] = (8 * (g0 + gi) + (lane & 7)) * (int)kS_bytes + ((lane >> 3) ^ (KXOR ? ((g0 + gi) & 1) : 0)) * 16;
+        voff = V16 ? (8 * g0 + ((lane >> 1) & 7)) * (int)vS_bytes + (2 * (lane >> 4) + (lane & 1)) * 16
+                   : (8 * g0 + ((lane >> 2) & 7)) * (int)vS_bytes + (4 * (lane >> 5) + (lane & 3)) * 16;
+        kdst = g0 * KBLK;
+        vdst = G::K_TILE + g0 * VBLK;
     }
     __device__ __forceinline__ void set_dst(lds_ptr slot) { dst = (uint32_t)(uintptr_t)slot; }
     // The DMA is issued from inline asm: hipcc then keeps no account of it -- issued through the builtin, every ds_read_b64_tr_b16 that
@@ -312,12 +317,12 @@ struct DmaStage {
                      : "v"(voffset), "s"(rsrc), "s"(lds_byte)
                      : "memory");
     }
-    // piece #N of tile t (N < LOADS: K, else V) -> ring slot `dst`
+    // piece #N of tile t (N < LOADS: K, else V) -> ring slot `dst`: key group gi = n / HALVES of this wave, 1-KiB piece j = n % HALVES
     template <int N>
     __device__ __forceinline__ void load(int t) const {
-        constexpr int j = N < LOADS ? N : N - LOADS;
-        if constexpr (N < LOADS) dma16(krsrc, dst + kdst + j * 1024, koff + t * ktile + j * 128);
-        else dma16(vrsrc, dst + vdst + j * 1024, voff + t * vtile + j * 128);
+        constexpr int n = N < LOADS ? N : N - LOADS, gi = n / HALVES, j = n % HALVES;
+        if constexpr (N < LOADS) dma16(krsrc, dst + kdst + gi * KBLK + j * 1024, koff[gi] + t * ktile + j * 128);
+        else dma16(vrsrc, dst + vdst + gi * VBLK + j * 1024, voff + t * vtile + gi * vgrp + j * 128);
     }
     // every piece this wave has issued has landed in LDS (then a barrier publishes it to the other waves)
     __device__ __forceinline__ void wait_all() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

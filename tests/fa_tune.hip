@@ -81,6 +81,17 @@ template <int D, bool CAUSAL>
 static std::vector<Variant> make_variants() {
     using T = __bf16;
     std::vector<Variant> v;
+#ifdef FA_TUNE_FOCUS   // a short list for many-round A/B runs of the knobs under study
+    v.push_back({"16x16x32", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1}>>});
+    v.push_back({"16x16x32 vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .m16 = 1}>>});
+    v.push_back({"16x16x32 VALU-first", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = 1, .m16 = 1}>>});
+    v.push_back({"16x16x32 VALU-first vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .valu_first = 1, .m16 = 1}>>});
+    v.push_back({"16x16x32 VALU-first npre 6 vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3, .valu_first = 1, .m16 = 1}>>});
+    v.push_back({"32x32x16", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0}>>});
+    v.push_back({"32x32x16 vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .m16 = 0}>>});
+    v.push_back({"32x32x16 MFMA-first", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = 0, .m16 = 0}>>});
+    return v;
+#endif
     v.push_back({"production (16x16x32 non-causal, 32x32x16 causal)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
     v.push_back({"16x16x32 MFMAs", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1}>>});
     v.push_back({"32x32x16 MFMAs", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0}>>});
@@ -98,6 +109,7 @@ static std::vector<Variant> make_variants() {
     if constexpr (D == 64) {
         v.push_back({"4 waves x 32 rows: 128-row units, two workgroups per CU", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.waves = 4, .m16 = CAUSAL ? 0 : -1}>>});
         v.push_back({"4 waves x 32 rows, the other engine", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.waves = 4, .m16 = CAUSAL ? 1 : 0}>>});
+        v.push_back({"4 waves x 32 rows, register staging", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.waves = 4, .m16 = CAUSAL ? 0 : -1, .dma = false}>>});
     }
     v.push_back({"unit streaming (no per-unit prologue)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.stream = 1}>>});
     v.push_back({"fp16 weights (FA_FLAG_F16_WEIGHTS)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>});

@@ -251,6 +251,10 @@ __global__ __launch_bounds__(512) void lds_image_kernel(const uint16_t* K, const
     lds_ptr smem = (lds_ptr)smem_raw;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     typename W::Stage st;
+    // the ring starts out full of NaN patterns: rows past S must arrive as zeros whatever LDS held before (a masked key's weight is 0,
+    // and 0 x NaN would still poison O)
+    for (int i = threadIdx.x; i < G::SLOT / 4; i += blockDim.x) *reinterpret_cast<FA_LDS uint32_t*>(smem + 4 * i) = 0xffffffffu;
+    __syncthreads();
     st.init((const char*)K, (const char*)V, D * 2, D * 2, S, wave, lane);
     st.load_all_into(0, smem);
     st.write_all(smem);
@@ -272,11 +276,10 @@ __global__ __launch_bounds__(512) void lds_image_kernel(const uint16_t* K, const
 }
 
 template <int D, bool DMA>
-static void test_lds_image() {
+static void test_lds_image(const int S = 64) {
     using G = TileGeom<D, 2>;
     using W = WaveCompute<KernelCfg<D, false, __bf16, 2, Opt{.m16 = 0, .dma = DMA}>>;
-    constexpr int S = 64;
-    std::vector<uint16_t> hk(S * D), hv(S * D);
+    std::vector<uint16_t> hk(64 * D, 0), hv(64 * D, 0);   // rows S .. 63 do not exist: expected 0
     for (int i = 0; i < S * D; ++i) { hk[i] = (uint16_t)(i + 1); hv[i] = (uint16_t)(0x8000 + i + 1); }   // "i + 1", V tagged
     uint16_t *dk, *dv, *dimg, *dkf, *dvf;
     HIP_CHECK(hipMalloc(&dk, S * D * 2)); HIP_CHECK(hipMalloc(&dv, S * D * 2));
@@ -341,6 +344,10 @@ __global__ __launch_bounds__(512) void lds_image16_kernel(const uint16_t* K, con
     lds_ptr smem = (lds_ptr)smem_raw;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     typename W::Stage st;
+    // the ring starts out full of NaN patterns: rows past S must arrive as zeros whatever LDS held before (a masked key's weight is 0,
+    // and 0 x NaN would still poison O)
+    for (int i = threadIdx.x; i < G::SLOT / 4; i += blockDim.x) *reinterpret_cast<FA_LDS uint32_t*>(smem + 4 * i) = 0xffffffffu;
+    __syncthreads();
     st.init((const char*)K, (const char*)V, D * 2, D * 2, S, wave, lane);
     st.load_all_into(0, smem);
     st.write_all(smem);
@@ -362,11 +369,10 @@ __global__ __launch_bounds__(512) void lds_image16_kernel(const uint16_t* K, con
 }
 
 template <int D, bool DMA>
-static void test_lds_image16() {
+static void test_lds_image16(const int S = 64) {
     using G = TileGeom<D, 2>;
     using W = WaveCompute16<KernelCfg<D, false, __bf16, 2, Opt{.m16 = 1, .dma = DMA}>>;
-    constexpr int S = 64;
-    std::vector<uint16_t> hk(S * D), hv(S * D);
+    std::vector<uint16_t> hk(64 * D, 0), hv(64 * D, 0);   // rows S .. 63 do not exist: expected 0
     for (int i = 0; i < S * D; ++i) { hk[i] = (uint16_t)(i + 1); hv[i] = (uint16_t)(0x8000 + i + 1); }
     uint16_t *dk, *dv, *dimg, *dkf, *dvf;
     HIP_CHECK(hipMalloc(&dk, S * D * 2)); HIP_CHECK(hipMalloc(&dv, S * D * 2));
@@ -534,6 +540,12 @@ int main() {
     test_lds_image<64, true>();
     test_lds_image16<128, true>();
     test_lds_image16<64, true>();
+    printf("ragged tile (S = 41 of 64 keys; LDS prefilled with NaN patterns):\n");
+    test_lds_image<128, false>(41);
+    test_lds_image<128, true>(41);
+    test_lds_image16<128, false>(41);
+    test_lds_image16<128, true>(41);
+    test_lds_image16<64, true>(41);
     measure_fp8_accumulation();
     printf("%d test(s) failed\n", g_fail);
     return g_fail;
