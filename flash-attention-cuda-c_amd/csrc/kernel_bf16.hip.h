@@ -68,6 +68,8 @@ struct Opt {
                                  // bf16, unpadded rows, 8 waves (KernelCfg::DMA); padded / fp8 / fp16-weights kernels convert or zero-fill
                                  // between the load and the LDS write and keep the register path.  The epilogue's LDS regions sit behind ring
                                  // slot 0: the next unit's tile 0 lands there while the epilogue runs
+    bool early_tile0 = false;    // (arm, measured +-0.7 %: nothing) LDS-DMA kernels: the next unit is decoded and its tile 0 requested BEFORE the finiteness check of the
+                                 // optimistic pass (under the check's barrier) instead of after it
     bool qk_pair_order = false;  // 32x32x16 engine, bf16: QK^T fragments ordered so that consecutive MFMAs share their Q fragment
     bool p_f16 = false;          // 16x16x32 engine: weights rounded to fp16 (11 significant bits) instead of bf16 (8), V staged as fp16, P.V
                                  // on v_mfma_f32_16x16x32_f16: the precision option behind FA_FLAG_F16_WEIGHTS (needs |V| <= 65504)
@@ -105,7 +107,8 @@ struct KernelCfg {
     static constexpr bool VALU_FIRST = O.valu_first < 0 ? !M16 : O.valu_first != 0;
     static constexpr bool P_F16 = M16 && O.p_f16;
     static constexpr bool QK_PAIR = O.qk_pair_order && ESZ_ == 2 && !M16;
-    static constexpr bool DMA = O.dma && ESZ_ == 2 && !O.pad && O.r == 1 && O.ring == 3 && !O.p_f16 && O.stream == 0;
+    static constexpr bool EARLY_TILE0 = O.early_tile0;
+    static constexpr bool DMA = O.dma && ESZ_ == 2 && !O.pad && O.r == 1 && O.ring == 3 && !O.p_f16;
     static constexpr bool STREAM = M16 && O.persist && O.optimistic && O.stream != 0;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
@@ -150,10 +153,14 @@ struct RowSink {
 
 // One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the
 // result has to be recomputed with max tracking (only ever true for TRACK = false).
-template <class C, bool TRACK>
+// before_check(): called once, after the last tile's barrier (no wave reads the ring any more) and before the finiteness check of
+// the optimistic pass -- the persistent kernel decodes the next unit and starts its tile 0 there, under the check's barrier.
+struct NoPreCheck { __device__ __forceinline__ void operator()() const {} };
+template <class C, bool TRACK, class PreCheck = NoPreCheck>
 __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>& w, typename WaveComputeOf<C>::Stage& st, lds_ptr smem,
                                                int n_tiles, int my_tiles, int q_row0, int lane,
-                                               unsigned long long (&acc)[15], bool tile0_in_flight, RowSink& sink) {
+                                               unsigned long long (&acc)[15], bool tile0_in_flight, RowSink& sink,
+                                               PreCheck&& before_check = PreCheck{}) {
     using G = TileGeom<C::D, C::ESZ>;
     constexpr bool CAUSAL = C::CAUSAL;
     constexpr int KVBLK = 64, SLOT = G::SLOT, KT = G::K_TILE;
@@ -268,6 +275,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
     }
     if constexpr (TRACK) return false;
     else {
+        before_check();
         unsigned long long tc0 = 0;
         if constexpr (C::STAMP) tc0 = cycle_stamp();
         const bool bad = __syncthreads_or(my_tiles > 0 && w.not_finite()) != 0;
@@ -366,7 +374,7 @@ __device__ __forceinline__ void stream_units16(const Params& p, lds_ptr smem) {
         UnitCtx<C> u0;
         u0.set(p, g, qb, wave);
         st.init(u0.Kh, u0.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
-        st.load_all(0);                                 // tile 0 and Q travel together (one HBM round trip)
+        st.load_all_into(0, smem);                      // tile 0 and Q travel together (one HBM round trip)
         if constexpr (C::COALESCED_Q) w.load_q_rows(u0.Qh, qSb, u0.q_row0, S, lane);
         else w.load_q(u0.Qh, qSb, u0.q_row0, S, lane, row_bytes);
     }
@@ -380,7 +388,7 @@ __device__ __forceinline__ void stream_units16(const Params& p, lds_ptr smem) {
         // lane-derived values are unit-invariant: an opaque copy keeps hipcc from hoisting (and spilling) them
         int lane_u = lane;
         asm volatile("" : "+v"(lane_u));
-        const int kbase = k16_read_base(lane_u), vbase = v16_read_base<D>(lane_u);
+        const int kbase = C::DMA ? kd16_read_base(lane_u, G::KBLK) : k16_read_base(lane_u), vbase = v16_read_base<D>(lane_u);
         int q_row0, n_tiles, my_tiles;
         {
             UnitCtx<C> cu;
@@ -403,10 +411,12 @@ __device__ __forceinline__ void stream_units16(const Params& p, lds_ptr smem) {
                 q_as_rows = false;
             }
             st.write_all(smem);
+            st.wait_all();
             __syncthreads();
-            st.load_all(1);          // past-the-end tiles read as zeros (buffer range check)
+            st.load_all_into(1, smem + SLOT);          // past-the-end tiles read as zeros (buffer range check)
             if (my_tiles > 0) w.qk_all(smem, kbase, sA);
             st.write_all(smem + SLOT);
+            st.wait_all();
             __syncthreads();
             so_cur = 0; so_nxt = SLOT; so_wr = 2 * SLOT;
         }
@@ -444,11 +454,13 @@ __device__ __forceinline__ void stream_units16(const Params& p, lds_ptr smem) {
                 const bool has_next = kind == 0;
                 w.template tile_step<false, false>(st, t + 2, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cs, ns, has_next,
                                                    has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, Sk, lane_u);
+                st.wait_all();   // (LDS-DMA staging: this wave's pieces of stream element t + 2 have landed; BEFORE the Q loads are issued)
                 fetch_next_q();
             } else {
                 // past this wave's causal diagonal: it stages its share of the stream, and at the seam fetches / scores for the next unit
-                st.load_all(st.select(t + 2));
+                st.load_all_into(st.select(t + 2), smem + so_wr);
                 st.write_all(smem + so_wr);
+                st.wait_all();
                 fetch_next_q();
                 if (last && next_live) {
                     w.pin_q();
@@ -513,7 +525,7 @@ __device__ __forceinline__ void stream_units16(const Params& p, lds_ptr smem) {
             UnitCtx<C> nx;
             unit_of(round, nx);
             st.init(nx.Kh, nx.Vh, kSb, vSb, Sk, wave, lane_u, row_bytes);
-            st.load_all(0);
+            st.load_all_into(0, smem);
             w.load_q(nx.Qh, qSb, nx.q_row0, S, lane_u, row_bytes);
             fresh = true;
         }
@@ -584,27 +596,47 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
         // An opaque copy of the lane id keeps them inside the pass.
         int lane_p = lane;
         if constexpr (C::PERSIST) asm volatile("" : "+v"(lane_p));
+        // Persistent grid: the next unit's tile 0 and Q are requested ahead, so that their HBM round trip runs under this unit's
+        // finiteness check and epilogue.  LDS-DMA staging needs no registers for the tile: it is decoded and started BEFORE the
+        // check (every wave is past the last tile's barrier, ring slot 0 is free, the epilogue works behind it); the register
+        // form waits until the pass is over (its staging registers and Q's are dead then).
+        bool more = false, prefetched = false;
+        UnitCtx<C> nxt;
+        auto prefetch_tile0 = [&]() {
+            more = work_unit<C>(p, ++round, g, qb);
+            if (more) {
+                nxt.set(p, g, qb, wave);
+                st.init(nxt.Kh, nxt.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
+                st.load_all_into(0, smem);
+            }
+            prefetched = true;
+        };
+        constexpr bool EARLY_PREFETCH = C::PERSIST && C::DMA && C::OPTIMISTIC && C::EARLY_TILE0;
         if constexpr (C::OPTIMISTIC) {
-            if (attention_pass<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true, sink)) {
+            auto before_check = [&]() { if constexpr (EARLY_PREFETCH) prefetch_tile0(); };
+            if (attention_pass<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true, sink, before_check)) {
                 sink.stored = false;   // whatever was written early came from an overflowed pass
+                if constexpr (EARLY_PREFETCH) {
+                    st.wait_all();     // the next unit's tile 0 is on its way into slot 0: let it land, then the ring is this unit's again
+                    st.init(cur.Kh, cur.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
+                }
                 attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false, sink);
+                if constexpr (EARLY_PREFETCH) {
+                    if (more) {        // ... and request it again
+                        st.init(nxt.Kh, nxt.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
+                        st.load_all_into(0, smem);
+                    }
+                }
             }
         } else {
             attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true, sink);
         }
 
-        // Persistent grid: request the next unit's Q and tile 0 now, so their HBM round trip runs under
-        // this unit's epilogue (Q's registers and the staging registers are dead once the pass is over).
-        bool more = false;
-        UnitCtx<C> nxt;
         unsigned long long t_nx0 = 0;
         if constexpr (C::STAMP) t_nx0 = cycle_stamp();
         if constexpr (C::PERSIST) {
-            more = work_unit<C>(p, ++round, g, qb);
+            if (!prefetched) prefetch_tile0();
             if (more) {
-                nxt.set(p, g, qb, wave);
-                st.init(nxt.Kh, nxt.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
-                st.load_all_into(0, smem);   // (DMA form: straight into ring slot 0 -- the epilogue below works behind it)
                 // (opaque lane: a hoisted per-lane Q address is spilled across the tile loop, and its reload's vmcnt(0)
                 // would make the Q loads wait for the tile-0 loads just issued)
                 int lane_n = lane;

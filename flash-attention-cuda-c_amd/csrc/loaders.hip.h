@@ -277,20 +277,25 @@ struct DmaStage {
     static constexpr int NL = 2 * LOADS, NW = 0;
     static constexpr int KBLK = G::KBLK;                          // bytes of one 8-key block of the K image
     static constexpr int VBLK = V16 ? G::DG * 256 : G::DB * 512;  // ... of the V image
-    u32x4 krsrc, vrsrc;    // raw buffer descriptors (stride 0; word 3 as __builtin_amdgcn_make_buffer_rsrc(..., 0x00020000))
+    u32x4 krsrc, vrsrc;    // raw buffer descriptors (stride 0; word 3 as __builtin_amdgcn_make_buffer_rsrc(..., 0x00020000)) the loads go through
+    // unit streaming (kernel_bf16.hip.h: stream_units16; same contract as BufStage): stream elements >= t_switch are tiles of the NEXT unit
+    uint64_t k1, v1, k2, v2;   // (head base addresses: the descriptors differ in nothing else)
+    int t_switch = 0x7fffffff;
     int koff[GPW], voff;   // per-lane source byte offset of piece 0 of key group gi inside a tile (K: the slot XOR depends on the group's parity)
     int ktile, vtile;      // bytes per 64-key tile step (scalar)
     int kgrp, vgrp;        // bytes per 8-key group step in global memory (scalar)
     int kdst, vdst;        // this wave's first block inside the K / V image (scalar)
     uint32_t dst;          // LDS byte address of the ring slot the next loads go to (scalar)
-    __device__ __forceinline__ static u32x4 descriptor(const char* base, int bytes) {
-        const uint64_t a = (uint64_t)base;
-        return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)bytes, 0x00020000u};
+    __device__ __forceinline__ static u32x4 descriptor(uint64_t a, uint32_t bytes) {
+        return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
     }
     __device__ __forceinline__ void init(const char* Kh, const char* Vh, int64_t kS_bytes, int64_t vS_bytes, int S, int wave, int lane,
                                          int row_bytes = D * 2) {
-        krsrc = descriptor(Kh, (int)((S - 1) * kS_bytes + row_bytes));
-        vrsrc = descriptor(Vh, (int)((S - 1) * vS_bytes + row_bytes));
+        k1 = (uint64_t)Kh;
+        v1 = (uint64_t)Vh;
+        krsrc = descriptor(k1, (uint32_t)((S - 1) * kS_bytes + row_bytes));
+        vrsrc = descriptor(v1, (uint32_t)((S - 1) * vS_bytes + row_bytes));
+        t_switch = 0x7fffffff;
         ktile = (int)(64 * kS_bytes);
         vtile = (int)(64 * vS_bytes);
         kgrp = (int)(8 * kS_bytes);
@@ -305,6 +310,24 @@ struct DmaStage {
         vdst = G::K_TILE + g0 * VBLK;
     }
     __device__ __forceinline__ void set_dst(lds_ptr slot) { dst = (uint32_t)(uintptr_t)slot; }
+    __device__ __forceinline__ void set_next(const char* Kh_next, const char* Vh_next, int at) {
+        k2 = (uint64_t)Kh_next;
+        v2 = (uint64_t)Vh_next;
+        t_switch = at;
+    }
+    __device__ __forceinline__ int select(int t) {   // scalar selects, no branch (see BufStage::select)
+        const bool nx = t >= t_switch;
+        krsrc = descriptor(nx ? k2 : k1, krsrc[2]);
+        vrsrc = descriptor(nx ? v2 : v1, vrsrc[2]);
+        return nx ? t - t_switch : t;
+    }
+    __device__ __forceinline__ void advance() {
+        k1 = k2;
+        v1 = v2;
+        krsrc = descriptor(k1, krsrc[2]);
+        vrsrc = descriptor(v1, vrsrc[2]);
+        t_switch = 0x7fffffff;
+    }
     // The DMA is issued from inline asm: hipcc then keeps no account of it -- issued through the builtin, every ds_read_b64_tr_b16 that
     // follows waits vmcnt(0) for it (the V^T reads of the SAME iteration), because the waitcnt pass cannot tell the ring slots apart.
     // Ordering is by hand instead: wait_all() before the barrier that publishes the tile.  M0 (the LDS destination) is written in the

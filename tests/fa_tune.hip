@@ -83,13 +83,9 @@ static std::vector<Variant> make_variants() {
     std::vector<Variant> v;
 #ifdef FA_TUNE_FOCUS   // a short list for many-round A/B runs of the knobs under study
     v.push_back({"16x16x32", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1}>>});
-    v.push_back({"16x16x32 vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .m16 = 1}>>});
-    v.push_back({"16x16x32 VALU-first", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = 1, .m16 = 1}>>});
-    v.push_back({"16x16x32 VALU-first vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .valu_first = 1, .m16 = 1}>>});
-    v.push_back({"16x16x32 VALU-first npre 6 vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3, .valu_first = 1, .m16 = 1}>>});
+    v.push_back({"16x16x32, next tile 0 requested after the check", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1, .early_tile0 = false}>>});
     v.push_back({"32x32x16", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0}>>});
-    v.push_back({"32x32x16 vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .m16 = 0}>>});
-    v.push_back({"32x32x16 MFMA-first", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = 0, .m16 = 0}>>});
+    v.push_back({"32x32x16, next tile 0 requested after the check", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0, .early_tile0 = false}>>});
     return v;
 #endif
     v.push_back({"production (16x16x32 non-causal, 32x32x16 causal)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
