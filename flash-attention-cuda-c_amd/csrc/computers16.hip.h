@@ -78,7 +78,7 @@ struct WaveCompute16 {
     u32x4 kf[NPRE];
     bf16x8 vf[VPRE + 1];
     uint32_t pw[QG][2][4];   // P(t) as packed bf16 pairs: [query group][k-step][word w = elements 2w, 2w+1]
-    float mx_a[QG], mx_b[QG], p_even, sum_a[QG], sum_b[QG];
+    float mx_a[QG], mx_b[QG], p_even, arg_odd, sum_a[QG], sum_b[QG];
     bool need;
     unsigned long long t_mid = 0, t_end = 0;   // STAMP builds only
 
@@ -219,7 +219,23 @@ struct WaveCompute16 {
     template <int E>
     __device__ __forceinline__ void exp_elem(const Scores16& cur, float c) {
         constexpr int kk = E / 16, qg = (E / 8) % 2, j = E % 8, kg = 2 * kk + (j >> 2), reg = j & 3;
-        const float p = fast_exp2(fmaf(cur.s[kg][qg][reg], c, -m[qg]));
+        float p;
+        if constexpr (C::PK_FMA) {
+            // registers (reg, reg + 1) of an accumulator are an aligned pair: one packed fma forms both exponent arguments in the
+            // slot of the even element (asm: hipcc splits a vector fma back into two v_fma_f32)
+            if constexpr ((j & 1) == 0) {
+                const f32x2 x = __builtin_shufflevector(cur.s[kg][qg], cur.s[kg][qg], reg, reg + 1);
+                const f32x2 c2 = {c, c}, nm2 = {-m[qg], -m[qg]};
+                f32x2 a;
+                asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(a) : "v"(x), "v"(c2), "v"(nm2));
+                arg_odd = a[1];
+                p = fast_exp2(a[0]);
+            } else {
+                p = fast_exp2(arg_odd);
+            }
+        } else {
+            p = fast_exp2(fmaf(cur.s[kg][qg][reg], c, -m[qg]));
+        }
         if constexpr (!C::SUM_MFMA) {
             if constexpr (j & 1) sum_b[qg] += p;
             else sum_a[qg] += p;

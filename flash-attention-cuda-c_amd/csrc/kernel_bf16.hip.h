@@ -70,6 +70,10 @@ struct Opt {
                                  // slot 0: the next unit's tile 0 lands there while the epilogue runs
     bool early_tile0 = false;    // (arm, measured +-0.7 %: nothing) LDS-DMA kernels: the next unit is decoded and its tile 0 requested BEFORE the finiteness check of the
                                  // optimistic pass (under the check's barrier) instead of after it
+    bool pk_fma = false;         // (arm, REJECTED: -7 %) 16x16x32 engine: the exponent arguments s*c - m of two adjacent accumulator registers
+                                 // from ONE v_pk_fma_f32 -- 16 VALU instructions fewer per wave-tile, no extra moves in the ISA, bitwise-equal
+                                 // results, and 7 % slower at every shape (profiles/r02_tune_s_packed_fma.log): next to MFMAs a packed-fp32
+                                 // instruction costs more than the two scalar ones it replaces
     bool qk_pair_order = false;  // 32x32x16 engine, bf16: QK^T fragments ordered so that consecutive MFMAs share their Q fragment
     bool p_f16 = false;          // 16x16x32 engine: weights rounded to fp16 (11 significant bits) instead of bf16 (8), V staged as fp16, P.V
                                  // on v_mfma_f32_16x16x32_f16: the precision option behind FA_FLAG_F16_WEIGHTS (needs |V| <= 65504)
@@ -108,6 +112,7 @@ struct KernelCfg {
     static constexpr bool P_F16 = M16 && O.p_f16;
     static constexpr bool QK_PAIR = O.qk_pair_order && ESZ_ == 2 && !M16;
     static constexpr bool EARLY_TILE0 = O.early_tile0;
+    static constexpr bool PK_FMA = O.pk_fma && M16;
     static constexpr bool DMA = O.dma && ESZ_ == 2 && !O.pad && O.r == 1 && O.ring == 3 && !O.p_f16;
     static constexpr bool STREAM = M16 && O.persist && O.optimistic && O.stream != 0;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
