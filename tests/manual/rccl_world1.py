@@ -1,3 +1,6 @@
+"""By hand on a GPU box:  python tests/manual/rccl_world1.py
+RCCL (torch.distributed backend "nccl") initialises on this image with a device id, and shard.reduce_max / reduce_sum -- the only
+collectives bench.py issues for N > 1 -- work on a float64 device scalar.  World size 1: the one-GPU box cannot host two RCCL ranks."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
