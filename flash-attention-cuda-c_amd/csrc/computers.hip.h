@@ -60,7 +60,8 @@ struct WaveCompute {
     static constexpr int NE = 32 * R;              // score elements per lane per tile
     static constexpr int SPAN = SA + (3 * SB) / 4; // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
-    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, false, true>, BufStage<D, ESZ, C::NWAVES, C::PAD>>;
+    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, false, true>,
+                                     std::conditional_t<C::DMA_K8, HybridStageFp8<D, C::NWAVES>, BufStage<D, ESZ, C::NWAVES, C::PAD>>>;
     using ScoresT = Scores<R>;
     static constexpr int NL = Stage::NL, NW = Stage::NW;
     static constexpr int WSTEP = 2 * NW <= SB / 2 + 1 ? 2 : 1;   // LDS writes sit in every WSTEP-th slot of the second half of phase B
@@ -176,7 +177,7 @@ struct WaveCompute {
     __host__ __device__ static constexpr int frag_u(int f) { return C::QK_PAIR ? f / 2 : f % FPH; }
     __host__ __device__ static constexpr int frag_kt(int f) { return C::QK_PAIR ? f % 2 : f / FPH; }
     __device__ __forceinline__ u32x4 k_read(lds_ptr kimg, int kbase, int f) const {
-        if constexpr (C::DMA) return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + frag_kt(f) * (4 * Stage::KBLK) + frag_u(f) * 256));
+        if constexpr (Stage::K_DMA) return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + frag_kt(f) * (4 * Stage::KBLK) + frag_u(f) * 256));
         else return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + frag_u(f) * 2048 + frag_kt(f) * 512));
     }
     // QK^T MFMA of fragment f, sub-step sub (fp8 only), row group r.  kprev = the fragment before kfrag (MX form only).

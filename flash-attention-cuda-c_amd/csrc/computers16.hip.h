@@ -163,7 +163,7 @@ struct WaveCompute16 {
 
     // K fragment f = (key group f / KS, k-step f % KS)
     __device__ __forceinline__ u32x4 k_read(lds_ptr kimg, int kbase, int f) const {
-        if constexpr (C::DMA) return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + (f / KS) * (2 * Stage::KBLK) + (f % KS) * 512));
+        if constexpr (Stage::K_DMA) return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + (f / KS) * (2 * Stage::KBLK) + (f % KS) * 512));
         else return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + (f % KS) * 4096 + (f / KS) * 256));
     }
     __device__ __forceinline__ void k_prefetch(lds_ptr, int) {}   // (4-slot-ring arm of the 32x32 kernel only)

@@ -114,6 +114,8 @@ struct KernelCfg {
     static constexpr bool EARLY_TILE0 = O.early_tile0;
     static constexpr bool PK_FMA = O.pk_fma && M16;
     static constexpr bool DMA = O.dma && ESZ_ == 2 && !O.pad && O.r == 1 && O.ring == 3 && !O.p_f16;
+    // fp8 inputs: K alone by LDS-DMA (V is widened to bf16 on its way into LDS and keeps the register path): loaders.hip.h, HybridStageFp8
+    static constexpr bool DMA_K8 = O.dma && ESZ_ == 1 && D_ == 128 && !O.pad && O.r == 1 && O.ring == 3 && O.waves == 0;
     static constexpr bool STREAM = M16 && O.persist && O.optimistic && O.stream != 0;
     static constexpr int NPRE = O.npre, VPRE = O.vpre, THR = O.thr, WG = O.wg;
     static constexpr int R = O.r;                    // 32-row query groups per wave (1 or 2)
@@ -130,7 +132,7 @@ struct KernelCfg {
     static constexpr int EP_WAVE_BYTES = 16 * (sizeof(OutT_) == 2 ? D_ * 2 : 256);
     static constexpr int EP_BYTES = NWAVES * EP_WAVE_BYTES;
     // LDS-DMA staging: the epilogue regions (QBLK rows of D 2-byte outputs, or of 64 floats) sit behind ring slot 0
-    static constexpr int EP_OFF = DMA ? TileGeom<D_, ESZ_>::SLOT : 0;
+    static constexpr int EP_OFF = (DMA || DMA_K8) ? TileGeom<D_, ESZ_>::SLOT : 0;
     static constexpr int EP_NEED = EP_OFF + (sizeof(OutT_) == 2 ? QBLK * D_ * 2 : (O.lds_epilogue32 ? QBLK * 256 : 0));
     static constexpr int LDS_BYTES = STREAM ? RING_BYTES + EP_BYTES : (EP_NEED > RING_BYTES ? EP_NEED : RING_BYTES);
     static_assert(LDS_BYTES <= 163840 - 256, "160 KiB of LDS per CU, 256 bytes of which __syncthreads_or takes statically");
@@ -175,7 +177,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
     w.init();
     using WC = WaveComputeOf<C>;
     constexpr int KBLK = (G::ROWB / 16) * 128;   // DMA form of the K image: bytes per 8-key block
-    const int kbase = C::DMA ? (C::M16 ? kd16_read_base(lane, KBLK) : kd_read_base(lane, KBLK)) : (C::M16 ? k16_read_base(lane) : k_read_base(lane));
+    const int kbase = WC::Stage::K_DMA ? (C::M16 ? kd16_read_base(lane, KBLK) : kd_read_base(lane, KBLK)) : (C::M16 ? k16_read_base(lane) : k_read_base(lane));
     const int vbase = C::M16 ? v16_read_base<C::D>(lane) : v_read_base(lane);
     const float c = p.scale_log2;
     auto needs_mask = [&](int t) { return (CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > S); };

@@ -128,6 +128,7 @@ struct BufStage {
     static constexpr int NL = 2 * LOADS;                         // loads per thread per tile
     static constexpr int VW = ESZ == 1 ? 2 : 1;                  // ds_write_b128 per V load (fp8 widens to bf16)
     static constexpr int NW = LOADS + LOADS * VW;                // LDS writes per thread per tile
+    static constexpr bool K_DMA = false;                         // (the K image is the chunk-major one)
     static_assert(8 % NWAVES == 0, "NWAVES must divide the 8 key groups of a tile");
     __amdgpu_buffer_rsrc_t krsrc, vrsrc;
     // Unit streaming (kernel_bf16.hip.h: stream_units16): tile indices >= t_switch belong to the NEXT unit's K / V (tile
@@ -276,6 +277,7 @@ struct DmaStage {
     static constexpr int LOADS = HALVES * GPW;                    // 1-KiB pieces per wave per tensor per tile
     static constexpr int NL = 2 * LOADS, NW = 0;
     static constexpr int KBLK = G::KBLK;                          // bytes of one 8-key block of the K image
+    static constexpr bool K_DMA = true;
     static constexpr int VBLK = V16 ? G::DG * 256 : G::DB * 512;  // ... of the V image
     u32x4 krsrc, vrsrc;    // raw buffer descriptors (stride 0; word 3 as __builtin_amdgcn_make_buffer_rsrc(..., 0x00020000)) the loads go through
     // unit streaming (kernel_bf16.hip.h: stream_units16; same contract as BufStage): stream elements >= t_switch are tiles of the NEXT unit
@@ -355,6 +357,46 @@ struct DmaStage {
     template <int N = 0> __device__ __forceinline__ void load_all(int t) const { if constexpr (N < NL) { load<N>(t); load_all<N + 1>(t); } }
     __device__ __forceinline__ void load_all_into(int t, lds_ptr slot) { set_dst(slot); load_all(t); }
     __device__ __forceinline__ void write_all(lds_ptr) const {}
+};
+
+// ---- fp8 inputs (Opt::dma, unpadded rows, 8 waves): K by LDS-DMA, V through registers -------------------------------------------
+// K rows are 128 bytes of e4m3: the tile's K image (8 KiB, DMA form with the 32x32x16 engine's slot swap) is eight 1-KiB pieces, one per
+// wave.  V has to be widened to bf16 between the load and the LDS write, so it keeps BufStage's register path (1 load, 2 ds_write_b128).
+// The DMA is issued BEFORE the V load of the same tile: hipcc's counted vmcnt for the V data then never waits on a younger DMA.
+template <int D, int NWAVES>
+struct HybridStageFp8 {
+    using G = TileGeom<D, 1>;
+    using VPath = BufStage<D, 1, NWAVES, false>;
+    static_assert(NWAVES == 8 && G::ROWB == 128, "fp8 K by DMA: 8 waves, 128-byte rows");
+    static constexpr int LOADS = 1, NL = 2, NW = 2;
+    static constexpr int KBLK = G::KBLK;
+    static constexpr bool K_DMA = true;
+    VPath v;               // (its K half stays unused: only load<1> / write<1>, write<2> are called)
+    u32x4 krsrc;
+    int koff, ktile, kdst;
+    uint32_t dst;
+    __device__ __forceinline__ void init(const char* Kh, const char* Vh, int64_t kS_bytes, int64_t vS_bytes, int S, int wave, int lane,
+                                         int row_bytes = D) {
+        v.init(Kh, Vh, kS_bytes, vS_bytes, S, wave, lane, row_bytes);
+        const uint64_t a = (uint64_t)Kh;
+        krsrc = u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)((S - 1) * kS_bytes + row_bytes), 0x00020000u};
+        ktile = (int)(64 * kS_bytes);
+        koff = (8 * wave + (lane & 7)) * (int)kS_bytes + ((lane >> 3) ^ (wave & 1)) * 16;
+        kdst = wave * KBLK;
+    }
+    __device__ __forceinline__ void set_dst(lds_ptr slot) { dst = (uint32_t)(uintptr_t)slot; }
+    template <int N>
+    __device__ __forceinline__ void load(int t) {
+        if constexpr (N == 0) DmaStage<128, 8, false, true>::dma16(krsrc, dst + kdst, koff + t * ktile);
+        else v.template load<1>(t);
+    }
+    template <int N>
+    __device__ __forceinline__ void write(lds_ptr slot_base) const { v.template write<N + 1>(slot_base); }
+    __device__ __forceinline__ void pin_all() {}
+    __device__ __forceinline__ void wait_all() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __device__ __forceinline__ void load_all(int t) { load<0>(t); load<1>(t); }
+    __device__ __forceinline__ void load_all_into(int t, lds_ptr slot) { set_dst(slot); load_all(t); }
+    __device__ __forceinline__ void write_all(lds_ptr s) const { write<0>(s); write<1>(s); }
 };
 
 }  // namespace fa

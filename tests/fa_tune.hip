@@ -143,7 +143,8 @@ static std::vector<Variant> make_variants() {
 template <bool CAUSAL>
 static std::vector<Variant> make_variants_fp8() {
     std::vector<Variant> v;
-    v.push_back({"fp8 production (MX: QK^T on 32x32x64 f8f6f4, unit scales)", launch_cfg<ProdCfg<128, CAUSAL, __bf16, 1>>});
+    v.push_back({"fp8 production (MX: QK^T on 32x32x64 f8f6f4, unit scales; K by LDS-DMA)", launch_cfg<ProdCfg<128, CAUSAL, __bf16, 1>>});
+    v.push_back({"fp8, K through registers (no LDS-DMA)", launch_cfg<KernelCfg<128, CAUSAL, __bf16, 1, Opt{.m16 = 0, .dma = false}>>});
     v.push_back({"fp8 QK^T on the non-scaled 32x32x16 fp8 MFMA", launch_cfg<KernelCfg<128, CAUSAL, __bf16, 1, Opt{.mxqk = 0}>>});
     return v;
 }
