@@ -420,6 +420,66 @@ static void test_lds_image16(const int S = 64) {
     HIP_CHECK(hipFree(dk)); HIP_CHECK(hipFree(dv)); HIP_CHECK(hipFree(dimg)); HIP_CHECK(hipFree(dkf)); HIP_CHECK(hipFree(dvf));
 }
 
+// fp8 inputs (e4m3 bytes, d = 128): the K image and K fragments of the 32x32x16 engine, K by LDS-DMA (production, HybridStageFp8) or through
+// registers.  Fragment f = (32-key half kt = f / FPH, 16-byte piece u = f % FPH): lane (r, h) holds bytes K[32kt + r][16(2u + h) .. +15].
+// (V is widened to bf16 on its way into LDS: covered end to end by the fp8 parity tests.)
+template <bool DMA>
+__global__ __launch_bounds__(512) void lds_image_fp8_kernel(const uint8_t* K, const uint8_t* V, int S, uint8_t* kfr) {
+    using C = KernelCfg<128, false, __bf16, 1, Opt{.dma = DMA}>;
+    static_assert(C::DMA_K8 == DMA && !C::M16);
+    using G = TileGeom<128, 1>;
+    using W = WaveCompute<C>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    lds_ptr smem = (lds_ptr)smem_raw;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < G::SLOT / 4; i += blockDim.x) *reinterpret_cast<FA_LDS uint32_t*>(smem + 4 * i) = 0xffffffffu;
+    __syncthreads();
+    typename W::Stage st;
+    st.init((const char*)K, (const char*)V, 128, 128, S, wave, lane);
+    st.load_all_into(0, smem);
+    st.write_all(smem);
+    st.wait_all();
+    __syncthreads();
+    if (wave == 0) {
+        W w;
+        const int kbase = DMA ? kd_read_base(lane, G::KBLK) : k_read_base(lane);
+        for (int f = 0; f < W::NF; ++f) {
+            const u32x4 kf = w.k_read(smem, kbase, f);
+            for (int e = 0; e < 4; ++e)
+                for (int b = 0; b < 4; ++b) kfr[(f * 64 + lane) * 16 + 4 * e + b] = (kf[e] >> (8 * b)) & 0xff;
+        }
+    }
+}
+
+template <bool DMA>
+static void test_lds_image_fp8(const int S = 64) {
+    using G = TileGeom<128, 1>;
+    using W = WaveCompute<KernelCfg<128, false, __bf16, 1, Opt{.dma = DMA}>>;
+    constexpr int D = 128;
+    std::vector<uint8_t> hk(64 * D, 0), hv(S * D, 0);     // rows S .. 63 do not exist: expected 0; e4m3 codes below 0x78 (no NaN / inf patterns)
+    for (int i = 0; i < S * D; ++i) hk[i] = (uint8_t)((i * 7 + 1) % 0x77);
+    uint8_t *dk, *dv, *dkf;
+    HIP_CHECK(hipMalloc(&dk, S * D)); HIP_CHECK(hipMalloc(&dv, S * D)); HIP_CHECK(hipMalloc(&dkf, W::NF * 64 * 16));
+    HIP_CHECK(hipMemcpy(dk, hk.data(), S * D, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dv, hv.data(), S * D, hipMemcpyHostToDevice));
+    HIP_CHECK(hipFuncSetAttribute((const void*)lds_image_fp8_kernel<DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G::SLOT));
+    hipLaunchKernelGGL((lds_image_fp8_kernel<DMA>), dim3(1), dim3(512), 3 * G::SLOT, nullptr, dk, dv, S, dkf);
+    HIP_CHECK(hipDeviceSynchronize());
+    std::vector<uint8_t> kf(W::NF * 64 * 16);
+    HIP_CHECK(hipMemcpy(kf.data(), dkf, kf.size(), hipMemcpyDeviceToHost));
+    long long bad = 0;
+    for (int f = 0; f < W::NF; ++f)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 16; ++j) {
+                const int kt = f / W::FPH, u = f % W::FPH, r = lane & 31, h = lane >> 5;
+                bad += kf[(f * 64 + lane) * 16 + j] != hk[(32 * kt + r) * D + 16 * (2 * u + h) + j];
+            }
+    char name[200];
+    snprintf(name, sizeof name, "lds image fp8 d=128%s, S=%d: K A-fragments hold bytes K[32kt+r][16(2u+h)+j]", DMA ? " (K by LDS-DMA)" : "", S);
+    report(name, bad, (long long)W::NF * 64 * 16);
+    HIP_CHECK(hipFree(dk)); HIP_CHECK(hipFree(dv)); HIP_CHECK(hipFree(dkf));
+}
+
 // ------------------------------------------------------------------------------------------------ (3) fp8 MFMA accumulation
 // How exactly does gfx950's fp8 MFMA sum its products?  (A measurement, not a pass/fail test: the fp8 LSE bound of
 // tests/test_fuzz_slice.py is derived from the figure printed here.)  One wave computes D = A.B over K = 128 as the kernel
@@ -546,6 +606,9 @@ int main() {
     test_lds_image16<128, false>(41);
     test_lds_image16<128, true>(41);
     test_lds_image16<64, true>(41);
+    test_lds_image_fp8<false>();
+    test_lds_image_fp8<true>();
+    test_lds_image_fp8<true>(41);
     measure_fp8_accumulation();
     printf("%d test(s) failed\n", g_fail);
     return g_fail;
