@@ -113,7 +113,7 @@ struct KernelCfg {
     static constexpr bool QK_PAIR = O.qk_pair_order && ESZ_ == 2 && !M16;
     static constexpr bool EARLY_TILE0 = O.early_tile0;
     static constexpr bool PK_FMA = O.pk_fma && M16;
-    static constexpr bool DMA = O.dma && ESZ_ == 2 && !O.pad && O.r == 1 && O.ring == 3 && !O.p_f16;
+    static constexpr bool DMA = O.dma && ESZ_ == 2 && !O.pad && O.ring == 3 && !O.p_f16;
     // fp8 inputs: K alone by LDS-DMA (V is widened to bf16 on its way into LDS and keeps the register path): loaders.hip.h, HybridStageFp8
     static constexpr bool DMA_K8 = O.dma && ESZ_ == 1 && D_ == 128 && !O.pad && O.r == 1 && O.ring == 3 && O.waves == 0;
     static constexpr bool STREAM = M16 && O.persist && O.optimistic && O.stream != 0;
