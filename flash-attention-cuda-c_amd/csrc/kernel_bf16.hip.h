@@ -4,12 +4,13 @@
 // kernels/computers.cuh:33-67 / kernels/loaders.cuh:132-156,177-201.  The reference commits a tile and
 // immediately waits for it on every cuda::pipeline (no load/compute overlap).
 //
-// One workgroup = 8 waves (two per SIMD, <= 256 VGPRs) processes UNITS of 256 query rows of one (batch, head), a
+// One workgroup = 8 waves (two per SIMD, 226-240 VGPRs in production) processes UNITS of 256 query rows of one (batch, head), a
 // wave owning 32 rows.  The grid is persistent: one workgroup per CU walks a static, balanced list of units
 // (work_unit) and requests the next unit's Q and KV tile 0 before it runs the current unit's epilogue.
 // KV tiles of 64 keys live in a 3-slot LDS ring [K image | V image] (loaders.hip.h).  Iteration t of a wave reads
-// K(t+1) and V(t) and stages tile t+2 into slot (t+2)%3 = slot (t-1)%3, last read in iteration t-1, which
-// every wave left at the previous barrier: ONE barrier per tile.  The loop is unrolled x2 with ping-pong
+// K(t+1) and V(t) and stages tile t+2 (LDS-DMA: loaders.hip.h) into slot (t+2)%3 = slot (t-1)%3, last read in
+// iteration t-1, which every wave left at the previous barrier: ONE barrier per tile (behind a vmcnt(0): the wave's own
+// DMA pieces have landed).  The loop is unrolled x2 with ping-pong
 // score registers so S(t+1) never has to be copied into S(t).  What happens inside a tile: computers.hip.h.
 // Tuning decisions and the measured alternatives (64 rows per wave, one unit per workgroup, ...) are the
 // fields of fa::Opt below.

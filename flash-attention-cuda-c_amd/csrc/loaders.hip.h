@@ -1,21 +1,26 @@
-// loaders.hip.h -- HBM -> registers -> LDS staging of K/V tiles and the LDS images they land in.
+// loaders.hip.h -- staging of K/V tiles from HBM into LDS, and the LDS images they land in.
 //
 // Counterpart of the reference's kernels/loaders.cuh: the LDS carve-up (:23-52), asyncBufferLoad
 // (:55-83), asyncWriteO (:85-112) and the two loader warps (:114-203).  Re-designed for CDNA4:
-//   * no dedicated loader warps and no cuda::pipeline: every wave stages 1/8 of each tile through
-//     registers, the loads issued inside the MFMA slots of the tile two iterations earlier and the
-//     ds_write_b128 inside later slots (computers.hip.h), so HBM/L2 latency hides under compute;
-//   * tiles are fetched with BUFFER loads: per-head descriptor in SGPRs, a per-lane byte offset that
-//     never changes, the tile offset one scalar-operand add -- no per-tile address arithmetic, and rows
-//     past the end of the sequence read as 0 through the hardware range check (no clamping);
-//   * each wave-instruction fetches 8 rows x 128 contiguous bytes (full cache lines) -- the
-//     reference's lane-contiguous fragments (loaders.cuh:57) are 32 rows x frag*4 B per request;
-//   * Q is never staged in LDS: each lane loads the MFMA B-fragments of its own query row once;
-//   * the K image is chunk-major  [row bytes/16][64 keys][16 B]  so the 32 lanes of a half-wave read
-//     512 contiguous bytes per ds_read_b128 (conflict-free without an XOR swizzle, immediates only);
-//   * the V image is bf16 [key/8][d/32][key%8][d%32] so that ds_read_b64_tr_b16 (hardware transpose)
-//     feeds V^T straight into the PV MFMA: each half-wave reads 256 contiguous bytes.  fp8 inputs are
-//     widened to bf16 (exactly) on their way into this image.
+//   * no dedicated loader warps and no cuda::pipeline: every wave stages 1/8 of each tile, the requests issued inside the
+//     MFMA slots of the tile two iterations earlier (computers*.hip.h), so HBM/L2 latency hides under compute;
+//   * production form (bf16, unpadded rows; fp8: K only): LDS-DMA -- `buffer_load_dwordx4 ... lds` writes the tile straight
+//     into LDS, no staging registers and no ds_write (DmaStage, HybridStageFp8 at the end of this file);
+//   * register form (BufStage: padded head dimensions, fp8 V, the fp16-weights option -- whatever transforms the tile on its
+//     way): buffer loads into registers, ds_write_b128 inside later slots;
+//   * either way tiles are fetched through BUFFER descriptors: per-head descriptor in SGPRs, a per-lane byte offset that
+//     never changes, the tile offset one scalar-operand add -- no per-tile address arithmetic, and rows past the end of the
+//     sequence arrive as 0 through the hardware range check (no clamping);
+//   * each wave-instruction fetches 8 rows x 128 contiguous bytes (full cache lines) -- the reference's lane-contiguous
+//     fragments (loaders.cuh:57) are 32 rows x frag*4 B per request;
+//   * Q is never staged through the K/V ring: each lane ends up with the MFMA B-fragments of its own query row, once;
+//   * K image, register form: chunk-major [row bytes/16][64 keys][16 B], so the 32 lanes of a half-wave read 512 contiguous
+//     bytes per ds_read_b128; LDS-DMA form: [key/8][chunk slot][key%8][16 B] (what a linear 1-KiB DMA piece can write while
+//     reading whole 128-byte lines), with the 32x32x16 engine's chunk slots of odd 8-key blocks swapped pairwise -- both
+//     conflict-free without a per-read XOR, one per-lane base + immediates;
+//   * the V image is bf16 [key/8][d/32][key%8][d%32] (32x32x16 engine) or [key/8][d/16][key%8][d%16] (16x16x32 engine) so that
+//     ds_read_b64_tr_b16 (hardware transpose) feeds V^T straight into the PV MFMA: each half-wave reads 256 contiguous
+//     bytes.  fp8 inputs are widened to bf16 (exactly) on their way into this image.
 #pragma once
 
 #include "utils.hip.h"
