@@ -31,6 +31,16 @@ def test_flop_convention_and_peak():
     assert bench.PEAK_BF16_TFLOPS == 256 * 4 * 1024 * 2.4e9 / 1e12 == 2516.5824 or abs(bench.PEAK_BF16_TFLOPS - 2516.58) < 0.05
 
 
+def test_provenance_hash_ignores_comments_and_white_space_only():
+    """profiles/provenance.py: a measurement stays attached to the sources while only comments / layout change."""
+    import provenance
+    a = 'int a = 1;  // one\n/* block\n comment */ const char* s = "// kept /* kept */";\nchar q = \'"\';\n'
+    b = 'int a=1;\nconst char* s   =   "// kept /* kept */"; // trailing\nchar q = \'"\';'
+    assert provenance.code_only(a) == provenance.code_only(b)
+    assert provenance.code_only(a) != provenance.code_only(a.replace("1", "2"))
+    assert provenance.code_only(a) != provenance.code_only(a.replace("// kept", "// changed"))
+
+
 def test_traffic_is_reported_only_with_matching_provenance(tmp_path, monkeypatch):
     """roofline.traffic comes from a committed PMC run, and only while the kernel sources are the ones it was taken on."""
     import provenance
