@@ -87,7 +87,6 @@ static int device_cus() {
 
 static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_dtype, float scale,
                      fa_launch_plan* plan) {
-    (void)causal;
     // bf16: d in {64,128} natively; any other multiple of 8 up to 128 runs the next larger instantiation with its
     // rows zero-padded on the fly (d/64 or d/128 of the MFMA work is useful -- still ~1000x the VALU kernel)
     const bool mfma_bf16 = dtype == FA_DTYPE_BF16 && d % 8 == 0 && d <= 128 && scale > 0.f;
@@ -108,10 +107,13 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
         plan->q_block_rows = calculateSizeBlockQ(d, dtype);
         plan->kv_block_rows = calculateSizeBlockKV(d, dtype);
         plan->threads = 512;
-        // 3-slot ring of [K image (input type) | V image (bf16)], at the instantiated head dimension
+        // 3-slot ring of [K image (input type) | V image (bf16)] at the instantiated head dimension, or ring slot 0 + the
+        // epilogue's staging regions where those are larger -- as carved up by the instantiation this problem launches (the
+        // engine depends on the mask, the staging form on padding: kernel_bf16.hip.h, KernelCfg::LDS_BYTES)
         const int dk = mfma_fp8 ? 128 : paddedDHead(d);
-        plan->lds_bytes = 3 * plan->kv_block_rows * dk * ((mfma_fp8 ? 1 : 2) + 2);
-        if (o_dtype == FA_DTYPE_F32 && plan->lds_bytes < 65536) plan->lds_bytes = 65536;   // fp32 epilogue staging (d = 64)
+        const bool pad = d != dk;
+        plan->lds_bytes = mfma_fp8 ? fp8_d128_lds_bytes(causal, pad, o_dtype)
+                                   : (dk == 128 ? bf16_d128_lds_bytes(causal, pad, o_dtype) : bf16_d64_lds_bytes(causal, pad, o_dtype));
         // persistent grid: one workgroup per CU (8 XCD groups x CUs/8), each walking ceil(units/grid) units;
         // with fewer units than CUs, one workgroup per unit
         const int nQ = getNumCta(S, plan->q_block_rows);

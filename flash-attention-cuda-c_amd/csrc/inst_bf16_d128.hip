@@ -38,4 +38,19 @@ hipError_t launch_bf16_d128(const Params& p, const fa_launch_plan& plan, bool ca
     return pad ? by_causal_lse<true>(p, plan, causal, o_dtype, st) : by_causal_lse<false>(p, plan, causal, o_dtype, st);
 }
 
+namespace {
+template <bool CAUSAL, bool PAD>
+int lds_by_out(int o_dtype) {
+    constexpr int D = 128, ESZ = 2;
+    if (o_dtype == FA_DTYPE_F32) return ProdCfg<D, CAUSAL, float, ESZ, false, PAD, false>::LDS_BYTES;
+    if (o_dtype == FA_DTYPE_BF16) return ProdCfg<D, CAUSAL, __bf16, ESZ, false, PAD, false>::LDS_BYTES;
+    return ProdCfg<D, CAUSAL, _Float16, ESZ, false, PAD, false>::LDS_BYTES;
+}
+}  // namespace
+
+int bf16_d128_lds_bytes(bool causal, bool pad, int o_dtype) {
+    return causal ? (pad ? lds_by_out<true, true>(o_dtype) : lds_by_out<true, false>(o_dtype))
+                  : (pad ? lds_by_out<false, true>(o_dtype) : lds_by_out<false, false>(o_dtype));
+}
+
 }  // namespace fa

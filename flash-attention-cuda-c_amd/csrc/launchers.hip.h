@@ -39,5 +39,10 @@ hipError_t launch_fp8_d128(const Params& p, const fa_launch_plan& plan, bool cau
 hipError_t launch_f32_d128(const Params& p, const fa_launch_plan& plan, bool causal, bool pad, int o_dtype, hipStream_t st);
 hipError_t launch_f32_d64(const Params& p, const fa_launch_plan& plan, bool causal, bool pad, int o_dtype, hipStream_t st);
 int f32_lds_bytes(int d_padded);
+// dynamic LDS of the instantiation the bf16 / fp8 entry points above would launch (the engine, and with it the ring and epilogue
+// carve-up, depends on the mask, the output type and whether the rows are padded): what flash_attention_plan reports
+int bf16_d128_lds_bytes(bool causal, bool pad, int o_dtype);
+int bf16_d64_lds_bytes(bool causal, bool pad, int o_dtype);
+int fp8_d128_lds_bytes(bool causal, bool pad, int o_dtype);
 
 }  // namespace fa

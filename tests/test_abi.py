@@ -91,11 +91,17 @@ def test_launch_plan(B, H, S, d, causal, dtype, kid, br, bc):
     else:
         assert p["grid"] == 8 * (-(-units // 8)) and p["grid"] >= units
     assert p["threads"] % 64 == 0 and p["lds_bytes"] <= 160 * 1024
-    if kid == 1:
-        dk = 64 if d <= 64 else 128                                 # the instantiation other head dimensions are padded to
-        assert p["lds_bytes"] == max(3 * 2 * 64 * dk * 2, 65536)  # 3-slot ring of K+V tiles; >= the fp32 epilogue's 64 KiB
-    if kid == 2:
-        assert p["lds_bytes"] == 3 * 64 * 128 * 3        # fp8 K image + bf16 V image, at the instantiated d = 128
+    if kid in (1, 2):
+        # 3-slot ring of [K image (input type) | V image (bf16)] tiles at the instantiated head dimension; the fp32 epilogue
+        # stages 256 rows x 64 floats -- behind ring slot 0 in the LDS-DMA kernels (unpadded rows: the next unit's tile 0 lands in
+        # slot 0 meanwhile), from the start of the ring in the register-staged ones (padded rows)
+        dk = 128 if kid == 2 or d > 64 else 64
+        slot = 64 * dk * ((1 if kid == 2 else 2) + 2)
+        ep_off = slot if d == dk else 0
+        assert p["lds_bytes"] == max(3 * slot, ep_off + 256 * 256)
+        # the plan is the launched instantiation's own figure: same problem with a bf16 output
+        pb = fa.plan(B, H, S, d, causal, dtype, fa.FA_DTYPE_BF16)
+        assert pb["lds_bytes"] == max(3 * slot, ep_off + 256 * dk * 2)
 
 
 def test_no_cpu_fallback_in_binding():
