@@ -431,6 +431,70 @@ struct WaveCompute {
         }
     }
 
+    // ---- ping-pong schedule (Opt::pingpong; bf16, one row group) ----------------------------------------------------------------
+    // A wave alternates an MFMA phase -- M(t): S(t+1) = K(t+1).Q^T and O^T += V(t)^T.P(t)^T, 2 x NA/... MFMAs and nothing but their
+    // fragment reads and the tile's DMA pieces between them -- with a softmax phase -- V(t): P(t+1) from S(t+1), no MFMA -- and the two
+    // waves of a SIMD run them in OPPOSITE order between workgroup barriers (kernel_bf16.hip.h: attention_pass_pp), so that at any time
+    // one of them feeds the MFMA pipe and the other the VALU.  One score buffer: S(t+1) is produced in M(t), consumed in V(t).
+    static constexpr int PNK = 8 < NF ? 8 : NF;   // K fragments in flight ahead of their MFMA in the MFMA phase
+    static constexpr int PNV = 6 < NB ? 6 : NB;   // V^T fragments
+    u32x4 kq[PNK];
+    bf16x8 vq[PNV];
+    template <bool QK, int I>
+    __device__ __forceinline__ void pp_slots(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase, Scores<R>& s) {
+        constexpr int NQ = QK ? NF : 0;           // QK^T slots, then NB P.V slots
+        if constexpr (I < NQ + NB) {
+            if constexpr (I < NQ) {
+                constexpr int f = I;
+                f32x16& acc = s.s[0][frag_kt(f)];
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc = mfma_32x32x16(__builtin_bit_cast(bf16x8, kq[f % PNK]), __builtin_bit_cast(bf16x8, qf[0][frag_u(f)]),
+                                    frag_u(f) == 0 ? z : acc);
+                if constexpr (f + PNK < NF) kq[f % PNK] = k_read(k_next, kbase, f + PNK);
+                if constexpr (f >= NF - PNV) {    // the last QK^T slots start the V^T window
+                    constexpr int v = f - (NF - PNV);
+                    vq[v % PNV] = v_frag(v_cur, vbase, v / DB, v % DB);
+                }
+            } else {
+                constexpr int v = I - NQ, s4 = v / DB, db = v % DB;
+                o[0][db] = mfma_32x32x16(vq[v % PNV], p_frag(0, s4), o[0][db]);
+                if constexpr (v + PNV < NB) vq[v % PNV] = v_frag(v_cur, vbase, (v + PNV) / DB, (v + PNV) % DB);
+            }
+            if constexpr ((I & 1) && (I >> 1) < NL) st.template load<(I >> 1)>(t_load);
+            __builtin_amdgcn_sched_barrier(0);
+            pp_slots<QK, I + 1>(st, t_load, k_next, v_cur, kbase, vbase, s);
+        }
+    }
+    // QK = false: the wave's last tile (no next tile to score)
+    template <bool QK>
+    __device__ __forceinline__ void m_phase(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase,
+                                            Scores<R>& s) {
+        static_assert(R == 1 && ESZ == 2 && !C::ASM_MFMA && !C::MXQK, "ping-pong schedule: bf16, one row group");
+        st.set_dst(wr_slot);
+        if constexpr (QK) {
+#pragma unroll
+            for (int i = 0; i < PNK; ++i) kq[i] = k_read(k_next, kbase, i);
+        } else {
+#pragma unroll
+            for (int v = 0; v < PNV; ++v) vq[v] = v_frag(v_cur, vbase, v / DB, v % DB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pp_slots<QK, 0>(st, t_load, k_next, v_cur, kbase, vbase, s);
+    }
+    // P(t+1) (packed bf16, pw) and the row-sum contribution from S(t+1); optimistic form: relative to the fixed reference m
+    template <int E = 0>
+    __device__ __forceinline__ void v_phase_elems(const Scores<R>& s, float c) {
+        if constexpr (E < NE) {
+            exp_elem<E>(s, c);
+            v_phase_elems<E + 1>(s, c);
+        }
+    }
+    __device__ __forceinline__ void v_phase(const Scores<R>& s, float c) {
+        sum_a[0] = sum_b[0] = 0.f;
+        v_phase_elems<0>(s, c);
+        l[0] += sum_a[0] + sum_b[0];
+    }
+
     // One tile: cur = S(t) (consumed), nxt = S(t+1) (produced).  LAST = the wave's last tile: no next tile, so
     // the step is instantiated without the QK^T MFMAs, their K reads, the max tracking and the rescale
     // (16 MFMAs per wave and unit that used to run on garbage "so that there is one hot code path").

@@ -75,6 +75,12 @@ struct Opt {
                                  // from ONE v_pk_fma_f32 -- 16 VALU instructions fewer per wave-tile, no extra moves in the ISA, bitwise-equal
                                  // results, and 7 % slower at every shape (profiles/r02_tune_s_packed_fma.log): next to MFMAs a packed-fp32
                                  // instruction costs more than the two scalar ones it replaces
+    bool pingpong = false;       // (arm, REJECTED: -10 %) 32x32x16 engine, bf16, LDS-DMA: every wave alternates an MFMA phase (QK^T of the next tile +
+                                 // P.V of this one, nothing else) with a softmax phase, the two waves of a SIMD in opposite phases between
+                                 // workgroup barriers (two per tile), 4-slot ring, one score buffer (attention_pass_pp).  Bitwise-equal results.
+                                 // The MFMA phase of a wave takes 1400 cycles for 32 MFMAs (1024 pipe cycles) however deep its fragment
+                                 // prefetch: a wave's own LDS reads and waits do not overlap its own MFMAs, so ONE wave cannot keep the pipe
+                                 // full, and the interleaved schedule, where both waves feed it, stays ahead (profiles/r02_tune_x_pingpong_phases.log)
     bool qk_pair_order = false;  // 32x32x16 engine, bf16: QK^T fragments ordered so that consecutive MFMAs share their Q fragment
     bool p_f16 = false;          // 16x16x32 engine: weights rounded to fp16 (11 significant bits) instead of bf16 (8), V staged as fp16, P.V
                                  // on v_mfma_f32_16x16x32_f16: the precision option behind FA_FLAG_F16_WEIGHTS (needs |V| <= 65504)
@@ -115,6 +121,7 @@ struct KernelCfg {
     static constexpr bool EARLY_TILE0 = O.early_tile0;
     static constexpr bool PK_FMA = O.pk_fma && M16;
     static constexpr bool DMA = O.dma && ESZ_ == 2 && !O.pad && O.ring == 3 && !O.p_f16;
+    static constexpr bool PP = O.pingpong && DMA && !M16 && O.r == 1 && O.waves == 0 && O.optimistic && !O.asm_mfma;
     // fp8 inputs: K alone by LDS-DMA (V is widened to bf16 on its way into LDS and keeps the register path): loaders.hip.h, HybridStageFp8
     static constexpr bool DMA_K8 = O.dma && ESZ_ == 1 && D_ == 128 && !O.pad && O.r == 1 && O.ring == 3 && O.waves == 0;
     static constexpr bool STREAM = M16 && O.persist && O.optimistic && O.stream != 0;
@@ -127,7 +134,7 @@ struct KernelCfg {
     static constexpr bool DBG_NOBAR = DBG & 1, DBG_NOLOAD = DBG & 2, DBG_PCONST = DBG & 4, DBG_M16 = DBG & 8;
     static constexpr int RING = O.ring;
     static_assert(RING == 3 || RING == 4, "3- or 4-slot ring");
-    static constexpr int RING_BYTES = RING * TileGeom<D_, ESZ_>::SLOT;
+    static constexpr int RING_BYTES = (PP ? 4 : RING) * TileGeom<D_, ESZ_>::SLOT;   // (ping-pong schedule: tile t+3 is staged in iteration t)
     // the fp32 LDS epilogue stages 256 rows x 64 floats: more than the ring at d = 64
     // streamed units: the epilogue's staging regions (per wave 16 rows x D 2-byte outputs, or x 64 floats) sit BEHIND the ring
     static constexpr int EP_WAVE_BYTES = 16 * (sizeof(OutT_) == 2 ? D_ * 2 : 256);
@@ -290,6 +297,80 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
         if constexpr (C::STAMP) acc[10] += cycle_stamp() - tc0;
         return bad;
     }
+}
+
+// The optimistic pass in the ping-pong schedule (Opt::pingpong; computers.hip.h: m_phase / v_phase).  Every wave runs
+//     [ M(t): S(t+1) = K(t+1).Q^T, O^T += V(t)^T.P(t)^T | barrier | V: P(t+1) from S(t+1) | barrier ]   per tile,
+// and waves 4-7 (group B: the SIMDs' second waves) enter that loop ONE barrier interval later than waves 0-3 (group A) -- they spend
+// the first interval forming P(0), which group A does before the loop, and group A spends one idle interval at the end -- so between
+// any two barriers one wave of a SIMD is in its MFMA phase and the other in its softmax phase.  4-slot ring: a wave issues its DMA
+// pieces of tile t+3 inside M(t), into the slot of tile t-1 (last read by group B's M(t-1), which ended at the previous barrier), and
+// waits for them (vmcnt(0)) before the barrier that ends its following V phase; the tile is first read two intervals after that.
+// Same contract as attention_pass<C, false>.
+template <class C, class PreCheck = NoPreCheck>
+__device__ __forceinline__ bool attention_pass_pp(const Params& p, WaveComputeOf<C>& w, typename WaveComputeOf<C>::Stage& st, lds_ptr smem,
+                                                  int n_tiles, int my_tiles, int q_row0, int lane, unsigned long long (&acc)[15],
+                                                  RowSink& sink, PreCheck&& before_check = PreCheck{}) {
+    using G = TileGeom<C::D, C::ESZ>;
+    using WC = WaveComputeOf<C>;
+    constexpr int KVBLK = 64, SLOT = G::SLOT, KT = G::K_TILE;
+    const int S = p.Sk;
+    const bool group_b = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4;
+    w.init();
+    const int kbase = kd_read_base(lane, G::KBLK), vbase = v_read_base(lane);
+    const float c = p.scale_log2;
+    auto needs_mask = [&](int t) { return (C::CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > S); };
+    typename WC::ScoresT s;
+
+    // prologue: tile 0 is on its way (requested with Q).  Slots 1 and 2 may still hold other waves' Q staging regions until the
+    // first barrier; then tiles 1 and 2 are requested, and S(0), its row max and P(0) are formed under their flight
+    st.wait_all();
+    __syncthreads();
+    st.load_all_into(1, smem + SLOT);
+    st.load_all_into(2, smem + 2 * SLOT);
+    if (my_tiles > 0) {
+        w.qk_all(smem, kbase, s);
+        if (needs_mask(0)) w.mask(s, 0, q_row0, S, lane);
+        w.first_max(s, c);
+        w.v_phase(s, c);
+    }
+    st.wait_all();
+    __syncthreads();
+    if (group_b) __syncthreads();                      // group B's leading interval (group A is in M(0))
+    int so_cur = 0, so_nxt = SLOT, so_wr = 3 * SLOT;   // ring slots of tiles t, t+1, t+3
+    for (int t = 0; t < n_tiles; ++t) {
+        const int kind = t + 1 < my_tiles ? 0 : (t < my_tiles ? 1 : 2);
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        if constexpr (C::STAMP) t0 = cycle_stamp();
+        __builtin_amdgcn_s_setprio(2);
+        if (kind == 0) w.template m_phase<true>(st, t + 3, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, s);
+        else if (kind == 1) w.template m_phase<false>(st, t + 3, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, s);
+        else st.load_all_into(t + 3, smem + so_wr);
+        __builtin_amdgcn_s_setprio(0);
+        if constexpr (C::STAMP) t1 = cycle_stamp();
+        __syncthreads();
+        if constexpr (C::STAMP) t2 = cycle_stamp();
+        if (kind == 0) {                               // P(t+1) from the S(t+1) just produced
+            if (needs_mask(t + 1)) w.mask(s, (t + 1) * KVBLK, q_row0, S, lane);
+            w.v_phase(s, c);
+        }
+        st.wait_all();                                 // this wave's pieces of tile t+3 have landed
+        if constexpr (C::STAMP) t3 = cycle_stamp();
+        __syncthreads();
+        if constexpr (C::STAMP) {                      // (tuner's columns: "phase A" = MFMA phase, "phase B" = softmax phase, "end-of-tile" = wait after M)
+            t4 = cycle_stamp();
+            if (kind == 0) { acc[1] += t1 - t0; acc[2] += t3 - t2; acc[3] += t2 - t1; acc[6] += 1; }
+            acc[5] += t4 - t3;
+        }
+        const int nx = so_nxt + SLOT == 4 * SLOT ? 0 : so_nxt + SLOT;
+        so_cur = so_nxt;
+        so_nxt = nx;
+        so_wr = so_wr + SLOT == 4 * SLOT ? 0 : so_wr + SLOT;
+    }
+    if (!group_b) __syncthreads();                     // group A's trailing interval (group B is in its last V phase)
+    before_check();
+    (void)sink;
+    return __syncthreads_or(my_tiles > 0 && w.not_finite()) != 0;
 }
 
 // Work assignment.  Non-persistent: one unit per workgroup (loaders.hip.h: unit_of_block).  Persistent: the
@@ -622,7 +703,10 @@ __global__ __launch_bounds__(64 * C::NWAVES, C::R == 1 ? 2 : 1) void fwd_mfma_ke
         constexpr bool EARLY_PREFETCH = C::PERSIST && C::DMA && C::OPTIMISTIC && C::EARLY_TILE0;
         if constexpr (C::OPTIMISTIC) {
             auto before_check = [&]() { if constexpr (EARLY_PREFETCH) prefetch_tile0(); };
-            if (attention_pass<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true, sink, before_check)) {
+            bool failed;
+            if constexpr (C::PP) failed = attention_pass_pp<C>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, sink, before_check);
+            else failed = attention_pass<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true, sink, before_check);
+            if (failed) {
                 sink.stored = false;   // whatever was written early came from an overflowed pass
                 if constexpr (EARLY_PREFETCH) {
                     st.wait_all();     // the next unit's tile 0 is on its way into slot 0: let it land, then the ring is this unit's again

@@ -82,10 +82,10 @@ static std::vector<Variant> make_variants() {
     using T = __bf16;
     std::vector<Variant> v;
 #ifdef FA_TUNE_FOCUS   // a short list for many-round A/B runs of the knobs under study (edit freely)
-    v.push_back({"16x16x32", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1}>>});
-    v.push_back({"16x16x32 EXPERIMENT no per-tile barrier (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1, .dbg = 1}>>});
     v.push_back({"32x32x16", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0}>>});
-    v.push_back({"32x32x16 EXPERIMENT no per-tile barrier (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0, .dbg = 1}>>});
+    v.push_back({"32x32x16 ping-pong phases", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0, .pingpong = true}>>});
+    v.push_back({"16x16x32", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1}>>});
+    v.push_back({"32x32x16 ping-pong phases STAMP", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.stamp = true, .m16 = 0, .pingpong = true}>>});
     return v;
 #endif
     v.push_back({"production (16x16x32 non-causal, 32x32x16 causal)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
