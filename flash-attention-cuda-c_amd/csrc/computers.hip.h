@@ -60,7 +60,7 @@ struct WaveCompute {
     static constexpr int NE = 32 * R;              // score elements per lane per tile
     static constexpr int SPAN = SA + (3 * SB) / 4; // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
-    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, false, true>,
+    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, false, true, C::DMA_SAVE_M0>,
                                      std::conditional_t<C::DMA_K8, HybridStageFp8<D, C::NWAVES>, BufStage<D, ESZ, C::NWAVES, C::PAD>>>;
     using ScoresT = Scores<R>;
     static constexpr int NL = Stage::NL, NW = Stage::NW;

@@ -60,7 +60,7 @@ struct WaveCompute16 {
     static constexpr int NE = 32;                  // score elements per lane per tile
     static constexpr int SPAN = SA + SB / 2;       // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
-    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, true, false>, BufStage<D, ESZ, C::NWAVES, C::PAD, true, C::P_F16>>;
+    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, true, false, C::DMA_SAVE_M0>, BufStage<D, ESZ, C::NWAVES, C::PAD, true, C::P_F16>>;
     // the P.V operand type: bf16, or fp16 with the fp16-weights option (weights rounded to 11 bits instead of 8; V staged as fp16)
     using pv_t = std::conditional_t<C::P_F16, f16x8, bf16x8>;
     using ScoresT = Scores16;

@@ -69,6 +69,7 @@ struct Opt {
                                  // bf16, unpadded rows, 8 waves (KernelCfg::DMA); padded / fp8 / fp16-weights kernels convert or zero-fill
                                  // between the load and the LDS write and keep the register path.  The epilogue's LDS regions sit behind ring
                                  // slot 0: the next unit's tile 0 lands there while the epilogue runs
+    bool dma_save_m0 = false;    // (arm) LDS-DMA statements save and restore M0 around themselves (2 more scalar instructions per piece)
     bool early_tile0 = false;    // (arm, measured +-0.7 %: nothing) LDS-DMA kernels: the next unit is decoded and its tile 0 requested BEFORE the finiteness check of the
                                  // optimistic pass (under the check's barrier) instead of after it
     bool pk_fma = false;         // (arm, REJECTED: -7 %) 16x16x32 engine: the exponent arguments s*c - m of two adjacent accumulator registers
@@ -119,6 +120,7 @@ struct KernelCfg {
     static constexpr bool P_F16 = M16 && O.p_f16;
     static constexpr bool QK_PAIR = O.qk_pair_order && ESZ_ == 2 && !M16;
     static constexpr bool EARLY_TILE0 = O.early_tile0;
+    static constexpr bool DMA_SAVE_M0 = O.dma_save_m0;
     static constexpr bool PK_FMA = O.pk_fma && M16;
     static constexpr bool DMA = O.dma && ESZ_ == 2 && !O.pad && O.ring == 3 && !O.p_f16;
     static constexpr bool PP = O.pingpong && DMA && !M16 && O.r == 1 && O.waves == 0 && O.optimistic && !O.asm_mfma;

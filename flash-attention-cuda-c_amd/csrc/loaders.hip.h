@@ -273,7 +273,7 @@ __device__ __forceinline__ int kd16_read_base(int lane, int blk_bytes) {  // 16x
     const int r = lane & 15, h4 = lane >> 4;
     return (r >> 3) * blk_bytes + h4 * 128 + (r & 7) * 16;
 }
-template <int D, int NWAVES, bool V16, bool KXOR>
+template <int D, int NWAVES, bool V16, bool KXOR, bool SAVE_M0 = false>
 struct DmaStage {
     using G = TileGeom<D, 2>;
     static constexpr int HALVES = G::ROWB / 128;
@@ -341,11 +341,20 @@ struct DmaStage {
     // statement that uses it and restored.  The instruction offset stays 0 (it would be added to the LDS address as well); the tile
     // offset goes into the VGPR offset so that the range check covers it.
     __device__ __forceinline__ static void dma16(const u32x4& rsrc, uint32_t lds_byte, int voffset) {
-        uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voffset), "s"(rsrc), "s"(lds_byte)
-                     : "memory");
+        if constexpr (SAVE_M0) {
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(voffset), "s"(rsrc), "s"(lds_byte)
+                         : "memory");
+        } else {
+            // (nothing else in these kernels lives in M0: it is written here, in the statement that uses it, and not restored --
+            //  two scalar instructions fewer per piece in the wave's serial instruction stream)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voffset), "s"(rsrc), "s"(lds_byte) : "memory", "m0");
+#pragma clang diagnostic pop
+        }
     }
     // piece #N of tile t (N < LOADS: K, else V) -> ring slot `dst`: key group gi = n / HALVES of this wave, 1-KiB piece j = n % HALVES
     template <int N>
