@@ -82,10 +82,10 @@ static std::vector<Variant> make_variants() {
     using T = __bf16;
     std::vector<Variant> v;
 #ifdef FA_TUNE_FOCUS   // a short list for many-round A/B runs of the knobs under study (edit freely)
-    v.push_back({"32x32x16", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0}>>});
-    v.push_back({"32x32x16 waits grouped by 2 (npre4 vpre3)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .m16 = 0, .wg = 2}>>});
-    v.push_back({"32x32x16 waits grouped by 2 (npre6 vpre3)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3, .m16 = 0, .wg = 2}>>});
-    v.push_back({"32x32x16 waits grouped by 4 (npre8 vpre5)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 8, .vpre = 5, .m16 = 0, .wg = 4}>>});
+    v.push_back({"16x16x32", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1}>>});
+    v.push_back({"16x16x32 vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .m16 = 1}>>});
+    v.push_back({"16x16x32 (again)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.thr = 9, .m16 = 1}>>});
+    v.push_back({"16x16x32 vpre 3 (again)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .thr = 9, .m16 = 1}>>});
     return v;
 #endif
     v.push_back({"production (16x16x32 non-causal, 32x32x16 causal)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
