@@ -6,7 +6,7 @@
 // (updateSoftmaxState), :93-113 (multiplyVAccumulateO).  Same algorithm -- blocked scores, running
 // (max, sum) per query row, rescaled accumulation of P.V -- re-designed for CDNA4:
 //
-//   * one WAVE owns R groups of 32 query rows (the reference: one warp per row); a KV tile is 64 keys;
+//   * one WAVE owns 32 query rows (the reference: one warp per row; R = 1 row group below); a KV tile is 64 keys;
 //   * scores come from v_mfma_f32_32x32x16_{bf16, fp8_fp8} in the SWAPPED orientation S^T = K.Q^T, so
 //     the 32 scores of one query row and key half sit in ONE lane's registers: row max / row sum are
 //     in-lane ops plus one v_permlane32_swap (the reference: cg::reduce + Bc-1 shuffles, utils.cuh:66-73);
@@ -47,7 +47,7 @@ struct Scores {          // raw scores of one 64-key tile: [row group][32-key ha
 
 template <class C>
 struct WaveCompute {
-    static constexpr int D = C::D, ESZ = C::ESZ, R = C::R;
+    static constexpr int D = C::D, ESZ = C::ESZ, R = 1;   // R: 32-row query groups per wave
     static constexpr int KS = D / 16;              // MFMA k-steps of one 32-key half of QK^T
     static constexpr int DB = D / 32;              // 32-wide d blocks of O^T
     static constexpr int NA = 2 * KS, NB = 4 * DB; // MFMAs per row group in phase A / phase B
@@ -60,7 +60,7 @@ struct WaveCompute {
     static constexpr int NE = 32 * R;              // score elements per lane per tile
     static constexpr int SPAN = SA + (3 * SB) / 4; // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
-    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, false, true, C::DMA_SAVE_M0>,
+    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, false, true>,
                                      std::conditional_t<C::DMA_K8, HybridStageFp8<D, C::NWAVES>, BufStage<D, ESZ, C::NWAVES, C::PAD>>>;
     using ScoresT = Scores<R>;
     static constexpr int NL = Stage::NL, NW = Stage::NW;
@@ -77,9 +77,6 @@ struct WaveCompute {
     bf16x8 vf[VPRE + 1];
     uint32_t pw[R][16];   // P(t) as packed bf16 pairs: word 4g+w = elements 8g+2w, 8g+2w+1
     float sum_a[R], sum_b[R], mx_a[R], mx_b[R], p_even;
-    f32x2 sum2[R];     // packed-math form of (sum_a, sum_b)
-    f32x2 c2, nm2[R];  // {c, c} and {-m, -m}: operands of the packed exponent fma
-    u32x4 dbg_frag = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // timing experiments only (Opt::dbg bit 2)
     bool need;         // tracked pass: lazy-rescale decision for S(t+1)
     unsigned long long t_mid = 0, t_end = 0;   // STAMP builds only
 
@@ -162,20 +159,12 @@ struct WaveCompute {
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int u = 0; u < FPH; ++u) {
-                if constexpr (C::ASM_MFMA) asm volatile("" : "+a"(qf[r][u]));   // Q's home is the accumulator file
-                else asm volatile("" : "+v"(qf[r][u]));
-            }
+            for (int u = 0; u < FPH; ++u) asm volatile("" : "+v"(qf[r][u]));
     }
 
-    __device__ __forceinline__ void k_prefetch(lds_ptr kimg, int kbase) {
-#pragma unroll
-        for (int i = 0; i < NPRE; ++i) kf[i] = k_read(kimg, kbase, i);
-    }
-    // Fragment f = (k-step, 32-key half).  Opt::qk_pair_order (bf16): half-major inside a k-step, (u, kt) = (f/2, f%2), so
-    // two consecutive MFMAs take the SAME Q fragment (one operand does not toggle); otherwise k-step-major, (f%FPH, f/FPH).
-    __host__ __device__ static constexpr int frag_u(int f) { return C::QK_PAIR ? f / 2 : f % FPH; }
-    __host__ __device__ static constexpr int frag_kt(int f) { return C::QK_PAIR ? f % 2 : f / FPH; }
+    // Fragment f = (k-step u = f % FPH, 32-key half kt = f / FPH)
+    __host__ __device__ static constexpr int frag_u(int f) { return f % FPH; }
+    __host__ __device__ static constexpr int frag_kt(int f) { return f / FPH; }
     __device__ __forceinline__ u32x4 k_read(lds_ptr kimg, int kbase, int f) const {
         if constexpr (Stage::K_DMA) return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + frag_kt(f) * (4 * Stage::KBLK) + frag_u(f) * 256));
         else return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + frag_u(f) * 2048 + frag_kt(f) * 512));
@@ -185,27 +174,14 @@ struct WaveCompute {
     __device__ __forceinline__ void qk_mfma(const u32x4& kprev, const u32x4& kfrag, Scores<R>& n) const {
         const u32x4& q = qf[RG][frag_u(F)];
         f32x16& acc = n.s[RG][frag_kt(F)];
-        constexpr bool first = (frag_u(F) == 0) && SUB == 0;   // first MFMA of this accumulation chain
         if constexpr (C::MXQK) {
             // fragments (F-1, F) = 64 contraction elements in ONE block-scaled MFMA, issued in the last slot of
             // the pair; the pair's other three slots carry only their softmax slice
-            static_assert(ESZ == 1 && !C::ASM_MFMA, "the MX form is for fp8 inputs");
+            static_assert(ESZ == 1, "the MX form is for fp8 inputs");
             if constexpr ((F & 1) && SUB == MPF - 1) acc = mfma_32x32x64_fp8_unit_scale(kprev, kfrag, qf[RG][(F - 1) % FPH], q, acc);
-        } else if constexpr (C::ASM_MFMA) {
-            if constexpr (ESZ == 2) {
-                mfma_qk_asm<first>(acc, kfrag, q);
-            } else {
-                const uint64_t a = (uint64_t)kfrag[2 * SUB] | ((uint64_t)kfrag[2 * SUB + 1] << 32);
-                const uint64_t b = (uint64_t)q[2 * SUB] | ((uint64_t)q[2 * SUB + 1] << 32);
-                mfma_qk_fp8_asm<first>(acc, a, b);
-            }
-        } else if constexpr (ESZ == 2) {
-            if constexpr (C::DBG_M16) acc = mfma_as_two_16x16x32(__builtin_bit_cast(bf16x8, kfrag), __builtin_bit_cast(bf16x8, q), acc, 0);
-            else acc = mfma_32x32x16(__builtin_bit_cast(bf16x8, kfrag), __builtin_bit_cast(bf16x8, q), acc);
         } else {
-            const uint64_t a = (uint64_t)kfrag[2 * SUB] | ((uint64_t)kfrag[2 * SUB + 1] << 32);
-            const uint64_t b = (uint64_t)q[2 * SUB] | ((uint64_t)q[2 * SUB + 1] << 32);
-            acc = mfma_32x32x16_fp8(a, b, acc);
+            static_assert(ESZ == 2, "the non-scaled form is for bf16 inputs");
+            acc = mfma_32x32x16(__builtin_bit_cast(bf16x8, kfrag), __builtin_bit_cast(bf16x8, q), acc);
         }
     }
     __device__ __forceinline__ static void zero(Scores<R>& n) {
@@ -218,7 +194,7 @@ struct WaveCompute {
     // S^T = K.Q^T for all row groups, compiler-scheduled: used once per pass for tile 0.
     template <int I = 0>
     __device__ __forceinline__ void qk_all(lds_ptr kimg, int kbase, Scores<R>& n) {
-        if constexpr (I == 0 && !C::ASM_MFMA) zero(n);
+        if constexpr (I == 0) zero(n);
         if constexpr (I < SA) {
             constexpr int f = I / (MPF * R), sub = (I % (MPF * R)) / R, rg = I % R;
             if constexpr (I % (MPF * R) == 0) kf[f % 2] = k_read(kimg, kbase, f);
@@ -230,7 +206,6 @@ struct WaveCompute {
     // Diagonal / ragged tile: key index > query index, or key index >= S  ->  -inf.
     // s[r][0][k] holds key kv0 + acc_row(k,h), s[r][1][k] key kv0 + 32 + acc_row(k,h); query q_row0 + 32r + (lane&31).
     __device__ __forceinline__ void mask(Scores<R>& n, int kv0, int q_row0, int S, int lane) const {
-        if constexpr (C::ASM_MFMA) mfma_drain();
         const int k0 = kv0 + 4 * (lane >> 5);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -254,7 +229,6 @@ struct WaveCompute {
     }
     // Tile 0 of a pass: m = its row max (m = -inf before; O and l are still 0).
     __device__ __forceinline__ void first_max(const Scores<R>& n, float c) {
-        if constexpr (C::ASM_MFMA) mfma_drain();
 #pragma unroll
         for (int r = 0; r < R; ++r) m[r] = fmaxf(m[r], max_both_halves(row_max(n, r)) * c);
     }
@@ -264,37 +238,9 @@ struct WaveCompute {
     template <int E>
     __device__ __forceinline__ void exp_elem(const Scores<R>& cur, float c) {
         constexpr int g = E / (8 * R), r = (E / 8) % R, j = E % 8, e = 8 * g + j;
-        if constexpr (C::PK) {
-            // two adjacent accumulator registers at a time: v_pk_fma_f32, 2 x v_exp_f32, v_pk_add_f32, v_cvt_pk
-            // (5 instead of 7 VALU instructions per pair), all in the slot of the even element
-            if constexpr ((e & 1) == 0) {
-                const f32x2 x = {cur.s[r][e >> 4][e & 15], cur.s[r][e >> 4][(e & 15) + 1]};
-                f32x2 a;   // asm: hipcc splits the vector fma back into two v_fma_f32
-                asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(a) : "v"(x), "v"(c2), "v"(nm2[r]));
-                const f32x2 p = {fast_exp2(a[0]), fast_exp2(a[1])};
-                sum2[r] += p;
-                pw[r][e >> 1] = pack_bf16(p[0], p[1]);
-                asm volatile("" : "+v"(sum2[r]));   // keep the add in this slot
-            }
-            return;
-        }
         const float x = cur.s[r][e >> 4][e & 15];
         const float p = fast_exp2(fmaf(x, c, -m[r]));
-        if constexpr (C::DOT2) {
-            // row sum from the packed bf16 pair: one v_dot2_f32_bf16 (p_lo*1 + p_hi*1 + acc) per two elements
-            // instead of two v_add_f32 -- and it sums exactly the rounded weights the P.V MFMA multiplies
-            if constexpr (e & 1) {
-                pw[r][e >> 1] = pack_bf16(p_even, p);
-                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-                const bf16x2 pp = __builtin_bit_cast(bf16x2, pw[r][e >> 1]);
-                const bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
-                if constexpr ((e >> 1) & 1) sum_b[r] = __builtin_amdgcn_fdot2_f32_bf16(pp, one, sum_b[r], false);
-                else sum_a[r] = __builtin_amdgcn_fdot2_f32_bf16(pp, one, sum_a[r], false);
-                asm volatile("" : "+v"(sum_a[r]), "+v"(sum_b[r]));
-            } else {
-                p_even = p;
-            }
-        } else if constexpr (e & 1) {
+        if constexpr (e & 1) {
             sum_b[r] += p;
             pw[r][e >> 1] = pack_bf16(p_even, p);
             asm volatile("" : "+v"(sum_a[r]), "+v"(sum_b[r]));   // keep the adds in this slot (hipcc sinks them)
@@ -349,52 +295,32 @@ struct WaveCompute {
         return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
 
-    // ONE asm statement per group, so hipcc emits one s_waitcnt (the smallest count) for all of its operands
-    template <int F, int K>
-    __device__ __forceinline__ void pin_k() {
-        static_assert(C::WG == 2 || C::WG == 4, "wait groups of 2 or 4 fragments");
-        if constexpr (C::WG == 2) asm volatile("" : "+v"(kf[F % NPRE]), "+v"(kf[(F + 1) % NPRE]));
-        else asm volatile("" : "+v"(kf[F % NPRE]), "+v"(kf[(F + 1) % NPRE]), "+v"(kf[(F + 2) % NPRE]), "+v"(kf[(F + 3) % NPRE]));
-    }
-    template <int V, int K>
-    __device__ __forceinline__ void pin_v() {
-        constexpr int W = VPRE + 1;
-        if constexpr (C::WG == 2) asm volatile("" : "+v"(vf[V % W]), "+v"(vf[(V + 1) % W]));
-        else asm volatile("" : "+v"(vf[V % W]), "+v"(vf[(V + 1) % W]), "+v"(vf[(V + 2) % W]), "+v"(vf[(V + 3) % W]));
-    }
-
     // ---- the slots -----------------------------------------------------------------------------
     // phase A slot I: fragment f = I/(MPF*R), then (sub, row group) = ((I % (MPF*R)) / R, I % R)
-    // LAST: the wave's final tile -- there is no S(t+1) to produce, so the QK^T MFMAs and their K reads are left out
-    template <int I, bool LAST = false>
+    template <int I>
     __device__ __forceinline__ void slots_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase,
                                             float c, const Scores<R>& cur, Scores<R>& nxt) {
         if constexpr (I < SA) {
             constexpr int f = I / (MPF * R), rem = I % (MPF * R), sub = rem / R, rg = rem % R;
             if constexpr (C::VALU_FIRST) exp_slot<I>(cur, c);   // softmax slice covers the fragment's LDS latency
-            if constexpr (!LAST) {
-                // one s_waitcnt per WG fragments instead of one per MFMA: "consume" the whole group here (the SIMD
-                // issues ~1 instruction per 5 cycles over all its waves, whatever the type: every s_waitcnt costs)
-                if constexpr (C::WG > 1 && !C::MXQK && rem == 0 && f % C::WG == 0) pin_k<f, 0>();
-                qk_mfma<f, sub, rg>(kf[(f + NPRE - 1) % NPRE], kf[f % NPRE], nxt);
-                if constexpr (C::MXQK) {
-                    // both fragments of a pair stay live until the pair's MFMA: refill the two window entries after it
-                    if constexpr (rem == MPF * R - 1 && (f & 1)) {
-                        if constexpr (f - 1 + NPRE < NF) kf[(f - 1) % NPRE] = k_read(k_next, kbase, f - 1 + NPRE);
-                        if constexpr (f + NPRE < NF) kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
-                    }
-                } else if constexpr (rem == MPF * R - 1 && f + NPRE < NF) {
-                    kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
+            qk_mfma<f, sub, rg>(kf[(f + NPRE - 1) % NPRE], kf[f % NPRE], nxt);
+            if constexpr (C::MXQK) {
+                // both fragments of a pair stay live until the pair's MFMA: refill the two window entries after it
+                if constexpr (rem == MPF * R - 1 && (f & 1)) {
+                    if constexpr (f - 1 + NPRE < NF) kf[(f - 1) % NPRE] = k_read(k_next, kbase, f - 1 + NPRE);
+                    if constexpr (f + NPRE < NF) kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
                 }
+            } else if constexpr (rem == MPF * R - 1 && f + NPRE < NF) {
+                kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
             }
             if constexpr (I >= SA - VPRE) {   // the last VPRE phase-A slots start the V^T window of phase B
                 constexpr int v = I - (SA - VPRE);
                 vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DB, v % DB);
             }
-            if constexpr (!C::DBG_NOLOAD && (I & 1) && (I >> 1) < NL) st.template load<(I >> 1)>(t_load);
+            if constexpr ((I & 1) && (I >> 1) < NL) st.template load<(I >> 1)>(t_load);
             if constexpr (!C::VALU_FIRST) exp_slot<I>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
-            slots_a<I + 1, LAST>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+            slots_a<I + 1>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         }
     }
     // phase B slot J: V^T fragment v = J/R (16-key step v/DB, d block v%DB), row group J%R
@@ -403,20 +329,7 @@ struct WaveCompute {
                                             const Scores<R>& cur, const Scores<R>& nxt) {
         if constexpr (J < SB) {
             constexpr int v = J / R, rg = J % R, s4 = v / DB, db = v % DB;
-            if constexpr (C::ASM_MFMA) {
-                // pad when the last bf16 pack of P group (s4, rg) was issued in the slot just before this one
-                constexpr int e_last = (s4 * R + rg) * 8 + 7;
-                mfma_pv_asm<(elem_slot(e_last) >= SA + J - 1)>(o[rg][db], vf[v % (VPRE + 1)], p_frag(rg, s4));
-            } else if constexpr (C::DBG_PCONST) {   // timing experiment: the exp / pack chain still runs, the MFMA does not wait for it
-                bf16x8 pa = p_frag(rg, s4);
-                asm volatile("" :: "v"(pa));
-                o[rg][db] = mfma_32x32x16(vf[v % (VPRE + 1)], __builtin_bit_cast(bf16x8, dbg_frag), o[rg][db]);
-            } else {
-                if constexpr (C::WG > 1 && rg == 0 && v % C::WG == 0) pin_v<v, 0>();
-                if constexpr (C::WG > 1 && J == SB / 2) st.pin_all();   // one vmcnt wait for the staged tile, not one per ds_write
-                if constexpr (C::DBG_M16) o[rg][db] = mfma_as_two_16x16x32(vf[v % (VPRE + 1)], p_frag(rg, s4), o[rg][db], 0);
-                else o[rg][db] = mfma_32x32x16(vf[v % (VPRE + 1)], p_frag(rg, s4), o[rg][db]);
-            }
+            o[rg][db] = mfma_32x32x16(vf[v % (VPRE + 1)], p_frag(rg, s4), o[rg][db]);
             if constexpr (rg == R - 1 && v + VPRE < NB) {
                 constexpr int vn = v + VPRE;
                 vf[vn % (VPRE + 1)] = v_frag(v_cur, vbase, vn / DB, vn % DB);
@@ -431,110 +344,33 @@ struct WaveCompute {
         }
     }
 
-    // ---- ping-pong schedule (Opt::pingpong; bf16, one row group) ----------------------------------------------------------------
-    // A wave alternates an MFMA phase -- M(t): S(t+1) = K(t+1).Q^T and O^T += V(t)^T.P(t)^T, 2 x NA/... MFMAs and nothing but their
-    // fragment reads and the tile's DMA pieces between them -- with a softmax phase -- V(t): P(t+1) from S(t+1), no MFMA -- and the two
-    // waves of a SIMD run them in OPPOSITE order between workgroup barriers (kernel_bf16.hip.h: attention_pass_pp), so that at any time
-    // one of them feeds the MFMA pipe and the other the VALU.  One score buffer: S(t+1) is produced in M(t), consumed in V(t).
-    static constexpr int PNK = 8 < NF ? 8 : NF;   // K fragments in flight ahead of their MFMA in the MFMA phase
-    static constexpr int PNV = 6 < NB ? 6 : NB;   // V^T fragments
-    u32x4 kq[PNK];
-    bf16x8 vq[PNV];
-    template <bool QK, int I>
-    __device__ __forceinline__ void pp_slots(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase, Scores<R>& s) {
-        constexpr int NQ = QK ? NF : 0;           // QK^T slots, then NB P.V slots
-        if constexpr (I < NQ + NB) {
-            if constexpr (I < NQ) {
-                constexpr int f = I;
-                f32x16& acc = s.s[0][frag_kt(f)];
-                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                acc = mfma_32x32x16(__builtin_bit_cast(bf16x8, kq[f % PNK]), __builtin_bit_cast(bf16x8, qf[0][frag_u(f)]),
-                                    frag_u(f) == 0 ? z : acc);
-                if constexpr (f + PNK < NF) kq[f % PNK] = k_read(k_next, kbase, f + PNK);
-                if constexpr (f >= NF - PNV) {    // the last QK^T slots start the V^T window
-                    constexpr int v = f - (NF - PNV);
-                    vq[v % PNV] = v_frag(v_cur, vbase, v / DB, v % DB);
-                }
-            } else {
-                constexpr int v = I - NQ, s4 = v / DB, db = v % DB;
-                o[0][db] = mfma_32x32x16(vq[v % PNV], p_frag(0, s4), o[0][db]);
-                if constexpr (v + PNV < NB) vq[v % PNV] = v_frag(v_cur, vbase, (v + PNV) / DB, (v + PNV) % DB);
-            }
-            if constexpr ((I & 1) && (I >> 1) < NL) st.template load<(I >> 1)>(t_load);
-            __builtin_amdgcn_sched_barrier(0);
-            pp_slots<QK, I + 1>(st, t_load, k_next, v_cur, kbase, vbase, s);
-        }
-    }
-    // QK = false: the wave's last tile (no next tile to score)
-    template <bool QK>
-    __device__ __forceinline__ void m_phase(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase,
-                                            Scores<R>& s) {
-        static_assert(R == 1 && ESZ == 2 && !C::ASM_MFMA && !C::MXQK, "ping-pong schedule: bf16, one row group");
-        st.set_dst(wr_slot);
-        if constexpr (QK) {
-#pragma unroll
-            for (int i = 0; i < PNK; ++i) kq[i] = k_read(k_next, kbase, i);
-        } else {
-#pragma unroll
-            for (int v = 0; v < PNV; ++v) vq[v] = v_frag(v_cur, vbase, v / DB, v % DB);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        pp_slots<QK, 0>(st, t_load, k_next, v_cur, kbase, vbase, s);
-    }
-    // P(t+1) (packed bf16, pw) and the row-sum contribution from S(t+1); optimistic form: relative to the fixed reference m
-    template <int E = 0>
-    __device__ __forceinline__ void v_phase_elems(const Scores<R>& s, float c) {
-        if constexpr (E < NE) {
-            exp_elem<E>(s, c);
-            v_phase_elems<E + 1>(s, c);
-        }
-    }
-    __device__ __forceinline__ void v_phase(const Scores<R>& s, float c) {
-        sum_a[0] = sum_b[0] = 0.f;
-        v_phase_elems<0>(s, c);
-        l[0] += sum_a[0] + sum_b[0];
-    }
-
-    // One tile: cur = S(t) (consumed), nxt = S(t+1) (produced).  LAST = the wave's last tile: no next tile, so
-    // the step is instantiated without the QK^T MFMAs, their K reads, the max tracking and the rescale
-    // (16 MFMAs per wave and unit that used to run on garbage "so that there is one hot code path").
+    // One tile: cur = S(t) (consumed), nxt = S(t+1) (produced; on the wave's last tile it is computed from a tile the wave
+    // does not need and ignored: one hot code path).
     // TRACK = true: running row max with lazy rescale (always safe).  TRACK = false: the optimistic
     // pass -- m stays the row max of tile 0 and no max / decision / rescale is issued.
-    template <bool TRACK, bool LAST = false>
+    template <bool TRACK>
     __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
                                               int kbase, int vbase, float c, const Scores<R>& cur, Scores<R>& nxt,
-                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane,
-                                              lds_ptr k_next2 = nullptr) {
+                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
         st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             sum_a[r] = sum_b[r] = 0.f;
-            sum2[r] = f32x2{0.f, 0.f};
-            nm2[r] = f32x2{-m[r], -m[r]};
             mx_a[r] = mx_b[r] = -INFINITY;
         }
-        c2 = f32x2{c, c};
-        if constexpr (!LAST) {
-            if constexpr (!C::ASM_MFMA) zero(nxt);   // asm form: the first MFMA of each chain has C = 0
-            if constexpr (C::RING != 4) {            // 4-slot ring: requested before the previous barrier (k_prefetch)
+        zero(nxt);
 #pragma unroll
-                for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
-            }
-        }
+        for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
         __builtin_amdgcn_sched_barrier(0);
-        slots_a<0, LAST>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        slots_a<0>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_mid = cycle_stamp();
-        slots_b<(TRACK && !LAST), 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
-        // 4-slot ring: K(t+2) has been complete since the previous barrier, so the first fragments of the next
-        // iteration are requested here, ahead of this iteration's barrier (their latency hides behind it)
-        if constexpr (C::RING == 4 && !LAST) k_prefetch(k_next2, kbase);
+        slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
 #pragma unroll
-        for (int r = 0; r < R; ++r) l[r] += C::PK ? sum2[r][0] + sum2[r][1] : sum_a[r] + sum_b[r];
+        for (int r = 0; r < R; ++r) l[r] += sum_a[r] + sum_b[r];
         // ONE rescale site: the masked (diagonal / ragged) tile only recomputes the scalar decision and
         // the row max.  (Two sites that both multiply O made hipcc copy all 64 accumulator registers
         // twice per tile on the common path.)
-        if constexpr (LAST) return;
         if (has_next && mask_next) {
             mask(nxt, kv0_next, q_row0, S, lane);
             if constexpr (TRACK) {
@@ -545,7 +381,6 @@ struct WaveCompute {
         }
         if constexpr (TRACK) {
             if (has_next && need) {
-                if constexpr (C::ASM_MFMA) mfma_drain();   // O was just written by asm MFMAs
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const float mn = fmaxf(m[r], mx_a[r]);
@@ -564,7 +399,6 @@ struct WaveCompute {
     // True iff a row sum or any O accumulator of this lane is inf / NaN (x*0 is NaN for both).  Four independent
     // chains: one dependent chain of 65 fmas costs ~500 cycles per unit.
     __device__ __forceinline__ bool not_finite() const {
-        if constexpr (C::ASM_MFMA) mfma_drain();
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -585,43 +419,6 @@ struct WaveCompute {
         if (lse_head && lane < 32 && qi < S) lse_head[qi] = (m[r] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
     }
 
-    // Direct form: divide by the row sum and store O[q][d].  A lane holds d = 32db + 8g4 + 4h + (0..3).
-    // Used for 4-byte outputs (the reference's float* O).  row0 = first row of the WAVE.
-    template <typename OutT>
-    __device__ __forceinline__ void store_o(char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S, int lane,
-                                            int orow_bytes = D * (int)sizeof(OutT)) {
-        if constexpr (C::ASM_MFMA) mfma_drain();
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float l_tot = sum_both_halves(l[r]);
-            store_lse(lse_head, l_tot, r, row0 + 32 * r, S, lane);
-            const float inv = 1.0f / l_tot;
-            const int qi = row0 + 32 * r + (lane & 31);
-            const int h = lane >> 5;
-            if (qi < S) {
-                char* dst = Oh + qi * oS_bytes;
-#pragma unroll
-                for (int db = 0; db < DB; ++db)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int d0 = 32 * db + 8 * g4 + 4 * h;
-                        if (C::PAD && d0 * (int)sizeof(OutT) >= orow_bytes) continue;   // columns past the real head dimension
-                        const float a = o[r][db][4 * g4 + 0] * inv, b = o[r][db][4 * g4 + 1] * inv;
-                        const float c2 = o[r][db][4 * g4 + 2] * inv, e = o[r][db][4 * g4 + 3] * inv;
-                        if constexpr (sizeof(OutT) == 4) {
-                            f32x4 v = {a, b, c2, e};
-                            *reinterpret_cast<f32x4*>(dst + d0 * 4) = v;
-                        } else if constexpr (__is_same(OutT, __bf16)) {
-                            u32x2 v = {pack_bf16(a, b), pack_bf16(c2, e)};
-                            *reinterpret_cast<u32x2*>(dst + d0 * 2) = v;
-                        } else {
-                            u32x2 v = {pack_f16(a, b), pack_f16(c2, e)};
-                            *reinterpret_cast<u32x2*>(dst + d0 * 2) = v;
-                        }
-                    }
-            }
-        }
-    }
     // 2-byte outputs: O^T accumulators -> this wave's private LDS region as a row-major [32R rows][D] tile
     // -> whole rows back out with 16-byte stores (each 16- or 8-lane group writes one full row).  The
     // direct form issues 16 eight-byte stores per lane that touch 32 rows each: ~8k cycles per workgroup,
@@ -634,7 +431,6 @@ struct WaveCompute {
         static_assert(sizeof(OutT) == 2, "LDS epilogue is for bf16 / f16 outputs");
         constexpr int ROWB = D * 2, CHUNKS = ROWB / 16;
         const int q = lane & 31, h = lane >> 5;
-        if constexpr (C::ASM_MFMA) mfma_drain();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const float l_tot = sum_both_halves(l[r]);
@@ -675,7 +471,6 @@ struct WaveCompute {
                                                   int lane, int orow_bytes = D * 4) {
         static_assert(sizeof(OutT) == 4, "for fp32 outputs");
         const int q = lane & 31, h = lane >> 5;
-        if constexpr (C::ASM_MFMA) mfma_drain();
         float inv[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {

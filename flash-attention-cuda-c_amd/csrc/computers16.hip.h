@@ -47,8 +47,8 @@ struct Scores16 {        // raw scores of one 64-key tile: [16-key group][16-row
 
 template <class C>
 struct WaveCompute16 {
-    static constexpr int D = C::D, ESZ = C::ESZ, R = 1;
-    static_assert(ESZ == 2 && C::R == 1, "16x16x32 path: bf16 inputs, 32 rows per wave");
+    static constexpr int D = C::D, ESZ = C::ESZ;
+    static_assert(ESZ == 2, "16x16x32 path: bf16 inputs");
     static constexpr int KS = D / 32;              // 32-wide k-steps of QK^T
     static constexpr int KG = 4, QG = 2;           // 16-key groups per tile, 16-row query groups per wave
     static constexpr int DG = D / 16;              // 16-wide d groups of O^T
@@ -60,7 +60,7 @@ struct WaveCompute16 {
     static constexpr int NE = 32;                  // score elements per lane per tile
     static constexpr int SPAN = SA + SB / 2;       // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
-    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, true, false, C::DMA_SAVE_M0>, BufStage<D, ESZ, C::NWAVES, C::PAD, true, C::P_F16>>;
+    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, true, false>, BufStage<D, ESZ, C::NWAVES, C::PAD, true, C::P_F16>>;
     // the P.V operand type: bf16, or fp16 with the fp16-weights option (weights rounded to 11 bits instead of 8; V staged as fp16)
     using pv_t = std::conditional_t<C::P_F16, f16x8, bf16x8>;
     using ScoresT = Scores16;
@@ -78,7 +78,7 @@ struct WaveCompute16 {
     u32x4 kf[NPRE];
     bf16x8 vf[VPRE + 1];
     uint32_t pw[QG][2][4];   // P(t) as packed bf16 pairs: [query group][k-step][word w = elements 2w, 2w+1]
-    float mx_a[QG], mx_b[QG], p_even, arg_odd, sum_a[QG], sum_b[QG];
+    float mx_a[QG], mx_b[QG], p_even, sum_a[QG], sum_b[QG];
     bool need;
     unsigned long long t_mid = 0, t_end = 0;   // STAMP builds only
 
@@ -166,7 +166,6 @@ struct WaveCompute16 {
         if constexpr (Stage::K_DMA) return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + (f / KS) * (2 * Stage::KBLK) + (f % KS) * 512));
         else return __builtin_bit_cast(u32x4, lds_read_b128(kimg, kbase + (f % KS) * 4096 + (f / KS) * 256));
     }
-    __device__ __forceinline__ void k_prefetch(lds_ptr, int) {}   // (4-slot-ring arm of the 32x32 kernel only)
     template <int F, int QGI>
     __device__ __forceinline__ void qk_mfma(const u32x4& kfrag, Scores16& n) const {
         n.s[F / KS][QGI] = mfma_16x16x32(__builtin_bit_cast(bf16x8, kfrag), __builtin_bit_cast(bf16x8, qf[QGI][F % KS]), n.s[F / KS][QGI]);
@@ -219,23 +218,7 @@ struct WaveCompute16 {
     template <int E>
     __device__ __forceinline__ void exp_elem(const Scores16& cur, float c) {
         constexpr int kk = E / 16, qg = (E / 8) % 2, j = E % 8, kg = 2 * kk + (j >> 2), reg = j & 3;
-        float p;
-        if constexpr (C::PK_FMA) {
-            // registers (reg, reg + 1) of an accumulator are an aligned pair: one packed fma forms both exponent arguments in the
-            // slot of the even element (asm: hipcc splits a vector fma back into two v_fma_f32)
-            if constexpr ((j & 1) == 0) {
-                const f32x2 x = __builtin_shufflevector(cur.s[kg][qg], cur.s[kg][qg], reg, reg + 1);
-                const f32x2 c2 = {c, c}, nm2 = {-m[qg], -m[qg]};
-                f32x2 a;
-                asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(a) : "v"(x), "v"(c2), "v"(nm2));
-                arg_odd = a[1];
-                p = fast_exp2(a[0]);
-            } else {
-                p = fast_exp2(arg_odd);
-            }
-        } else {
-            p = fast_exp2(fmaf(cur.s[kg][qg][reg], c, -m[qg]));
-        }
+        const float p = fast_exp2(fmaf(cur.s[kg][qg][reg], c, -m[qg]));
         if constexpr (!C::SUM_MFMA) {
             if constexpr (j & 1) sum_b[qg] += p;
             else sum_a[qg] += p;
@@ -307,7 +290,7 @@ struct WaveCompute16 {
                 constexpr int v = I - (SA - VPRE);
                 vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DG, v % DG);
             }
-            if constexpr (!C::DBG_NOLOAD && (I & 1) && (I >> 1) < NL) st.template load<(I >> 1)>(t_load);
+            if constexpr ((I & 1) && (I >> 1) < NL) st.template load<(I >> 1)>(t_load);
             if constexpr (!C::VALU_FIRST) exp_slot<I>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
             slots_a<I + 1>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
@@ -335,16 +318,11 @@ struct WaveCompute16 {
         }
     }
 
-    struct NoHook { __device__ __forceinline__ void operator()() const {} };
     // One tile: cur = S(t) (consumed), nxt = S(t+1) (produced).  Same contract as WaveCompute::tile_step.
-    // between(): called between the two phases (unit streaming: the next unit's Q fragments are requested there, when this
-    // unit's Q is dead -- the loads land under the P.V phase).
-    template <bool TRACK, bool LAST = false, class Between = NoHook>
+    template <bool TRACK>
     __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
                                               int kbase, int vbase, float c, const Scores16& cur, Scores16& nxt,
-                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane,
-                                              lds_ptr = nullptr, Between&& between = Between{}) {
-        static_assert(!LAST, "the 16x16x32 path has no separate last-tile step");
+                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
             mx_a[qg] = mx_b[qg] = -INFINITY;
@@ -354,11 +332,9 @@ struct WaveCompute16 {
         st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
-        if constexpr (C::STREAM) t_load = st.select(t_load);   // the stream element's own unit and tile index
         __builtin_amdgcn_sched_barrier(0);
         slots_a<0>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_mid = cycle_stamp();
-        between();
         slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
         if constexpr (!C::SUM_MFMA) {
@@ -412,38 +388,6 @@ struct WaveCompute16 {
         if (lse_head && lane < 16 && qi < S) lse_head[qi] = (m[qg] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
     }
 
-    // Direct form: a lane holds d = 16*dg + 4*h4 + (0..3) of query row0 + 16*qg + (lane&15).
-    template <typename OutT>
-    __device__ __forceinline__ void store_o(char* Oh, float* lse_head, int64_t oS_bytes, int row0, int S, int lane,
-                                            int orow_bytes = D * (int)sizeof(OutT)) {
-#pragma unroll
-        for (int qg = 0; qg < QG; ++qg) {
-            const float l_tot = row_sum_total(qg);
-            store_lse(lse_head, l_tot, qg, row0, S, lane);
-            const float inv = 1.0f / l_tot;
-            const int qi = row0 + 16 * qg + (lane & 15);
-            const int h4 = lane >> 4;
-            if (qi < S) {
-                char* dst = Oh + qi * oS_bytes;
-#pragma unroll
-                for (int dg = 0; dg < DG; ++dg) {
-                    const int d0 = 16 * dg + 4 * h4;
-                    if (C::PAD && d0 * (int)sizeof(OutT) >= orow_bytes) continue;   // columns past the real head dimension
-                    const float a = o[qg][dg][0] * inv, b = o[qg][dg][1] * inv, c2 = o[qg][dg][2] * inv, e = o[qg][dg][3] * inv;
-                    if constexpr (sizeof(OutT) == 4) {
-                        f32x4 v = {a, b, c2, e};
-                        *reinterpret_cast<f32x4*>(dst + d0 * 4) = v;
-                    } else if constexpr (__is_same(OutT, __bf16)) {
-                        u32x2 v = {pack_bf16(a, b), pack_bf16(c2, e)};
-                        *reinterpret_cast<u32x2*>(dst + d0 * 2) = v;
-                    } else {
-                        u32x2 v = {pack_f16(a, b), pack_f16(c2, e)};
-                        *reinterpret_cast<u32x2*>(dst + d0 * 2) = v;
-                    }
-                }
-            }
-        }
-    }
     // 2-byte outputs through this wave's private LDS region, one query group (16 rows) at a time: row-major [16 rows][D], 16-byte
     // chunk c of row q at chunk c ^ (q & mask); whole rows back out with 16-byte stores.  region: 16*D*2 bytes, not aliased by
     // anything live.  (The LDS executes a wave's accesses in order, so the second group's writes cannot overtake the first

@@ -136,10 +136,6 @@ struct BufStage {
     static constexpr bool K_DMA = false;                         // (the K image is the chunk-major one)
     static_assert(8 % NWAVES == 0, "NWAVES must divide the 8 key groups of a tile");
     __amdgpu_buffer_rsrc_t krsrc, vrsrc;
-    // Unit streaming (kernel_bf16.hip.h: stream_units16): tile indices >= t_switch belong to the NEXT unit's K / V (tile
-    // t - t_switch of the heads at k2 / v2), so one continuous tile stream crosses the seam between two units.
-    const char *k1 = nullptr, *v1 = nullptr, *k2 = nullptr, *v2 = nullptr;
-    int t_switch = 0x7fffffff, krec = 0, vrec = 0;
     int koff, voff;        // per-lane byte offset of load 0 inside a tile (constant)
     int klds, vlds;        // per-lane LDS byte offset of write 0 inside the K / V image
     int ktile, vtile;      // bytes per 64-key tile step (scalar)
@@ -151,13 +147,8 @@ struct BufStage {
                                          int wave, int lane, int row_bytes = G::ROWB) {
         // descriptor inputs are blockIdx / kernarg derived -> wave-uniform; num_records = the head's extent, to
         // the last byte of its last row (a strided view's rows are followed by other heads' data, or by nothing)
-        krec = (int)((S - 1) * kS_bytes + row_bytes);
-        vrec = (int)((S - 1) * vS_bytes + row_bytes);
-        k1 = Kh;
-        v1 = Vh;
-        krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, krec, 0x00020000);
-        vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, vrec, 0x00020000);
-        t_switch = 0x7fffffff;
+        krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (int)((S - 1) * kS_bytes + row_bytes), 0x00020000);
+        vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (int)((S - 1) * vS_bytes + row_bytes), 0x00020000);
         ktile = (int)(64 * kS_bytes);
         vtile = (int)(64 * vS_bytes);
         kgrp = (int)(8 * kS_bytes);
@@ -178,27 +169,6 @@ struct BufStage {
                 vok[hf] = (vc + 8 * hf) * 16 < row_bytes;
             }
         }
-    }
-    // the stream continues into the next unit (same shapes and strides, other heads) from tile index `at` on
-    __device__ __forceinline__ void set_next(const char* Kh_next, const char* Vh_next, int at) {
-        k2 = Kh_next;
-        v2 = Vh_next;
-        t_switch = at;
-    }
-    // Once per iteration, before its loads: point the descriptors at the unit that owns stream element t and return the tile
-    // index inside that unit.  Scalar selects, no branch (a branch inside the slot sequence splits its basic block and lets hipcc
-    // sink the softmax arithmetic of the slots before it behind it).
-    __device__ __forceinline__ int select(int t) {
-        const bool nx = t >= t_switch;
-        krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(nx ? k2 : k1), 0, krec, 0x00020000);
-        vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(nx ? v2 : v1), 0, vrec, 0x00020000);
-        return nx ? t - t_switch : t;
-    }
-    // ... and the next unit becomes the current one: tile indices restart at 0
-    __device__ __forceinline__ void advance() {
-        k1 = k2;
-        v1 = v2;
-        t_switch = 0x7fffffff;
     }
     __device__ __forceinline__ static u32x4 keep_if(bool ok, u32x4 v) {
         const u32x4 z = {0u, 0u, 0u, 0u};
@@ -237,11 +207,6 @@ struct BufStage {
             lds_write_b128(slot_base + G::K_TILE, vlds + n * (G::DB * 512) + W * 16, fp8x8_to_bf16x8(src[2 * W], src[2 * W + 1]));
         }
     }
-    __device__ __forceinline__ void pin_all() {   // wait for every staged load here: one asm statement = one s_waitcnt
-        static_assert(NL == 2 || NL == 4, "pin_all spells out its operands");
-        if constexpr (NL == 2) asm volatile("" : "+v"(r[0]), "+v"(r[1]));
-        else asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
-    }
     template <int N = 0> __device__ __forceinline__ void load_all_to(u32x4 (&dst)[NL], int t) const { if constexpr (N < NL) { load_to<N>(dst, t); load_all_to<N + 1>(dst, t); } }
     template <int N = 0> __device__ __forceinline__ void write_all_from(const u32x4 (&src)[NL], lds_ptr s) const { if constexpr (N < NW) { write_from<N>(src, s); write_all_from<N + 1>(src, s); } }
     template <int N = 0> __device__ __forceinline__ void load_all(int t) { if constexpr (N < NL) { load<N>(t); load_all<N + 1>(t); } }
@@ -273,7 +238,7 @@ __device__ __forceinline__ int kd16_read_base(int lane, int blk_bytes) {  // 16x
     const int r = lane & 15, h4 = lane >> 4;
     return (r >> 3) * blk_bytes + h4 * 128 + (r & 7) * 16;
 }
-template <int D, int NWAVES, bool V16, bool KXOR, bool SAVE_M0 = false>
+template <int D, int NWAVES, bool V16, bool KXOR>
 struct DmaStage {
     using G = TileGeom<D, 2>;
     static constexpr int HALVES = G::ROWB / 128;
@@ -285,9 +250,6 @@ struct DmaStage {
     static constexpr bool K_DMA = true;
     static constexpr int VBLK = V16 ? G::DG * 256 : G::DB * 512;  // ... of the V image
     u32x4 krsrc, vrsrc;    // raw buffer descriptors (stride 0; word 3 as __builtin_amdgcn_make_buffer_rsrc(..., 0x00020000)) the loads go through
-    // unit streaming (kernel_bf16.hip.h: stream_units16; same contract as BufStage): stream elements >= t_switch are tiles of the NEXT unit
-    uint64_t k1, v1, k2, v2;   // (head base addresses: the descriptors differ in nothing else)
-    int t_switch = 0x7fffffff;
     int koff[GPW], voff;   // per-lane source byte offset of piece 0 of key group gi inside a tile (K: the slot XOR depends on the group's parity)
     int ktile, vtile;      // bytes per 64-key tile step (scalar)
     int kgrp, vgrp;        // bytes per 8-key group step in global memory (scalar)
@@ -298,11 +260,8 @@ struct DmaStage {
     }
     __device__ __forceinline__ void init(const char* Kh, const char* Vh, int64_t kS_bytes, int64_t vS_bytes, int S, int wave, int lane,
                                          int row_bytes = D * 2) {
-        k1 = (uint64_t)Kh;
-        v1 = (uint64_t)Vh;
-        krsrc = descriptor(k1, (uint32_t)((S - 1) * kS_bytes + row_bytes));
-        vrsrc = descriptor(v1, (uint32_t)((S - 1) * vS_bytes + row_bytes));
-        t_switch = 0x7fffffff;
+        krsrc = descriptor((uint64_t)Kh, (uint32_t)((S - 1) * kS_bytes + row_bytes));
+        vrsrc = descriptor((uint64_t)Vh, (uint32_t)((S - 1) * vS_bytes + row_bytes));
         ktile = (int)(64 * kS_bytes);
         vtile = (int)(64 * vS_bytes);
         kgrp = (int)(8 * kS_bytes);
@@ -317,44 +276,18 @@ struct DmaStage {
         vdst = G::K_TILE + g0 * VBLK;
     }
     __device__ __forceinline__ void set_dst(lds_ptr slot) { dst = (uint32_t)(uintptr_t)slot; }
-    __device__ __forceinline__ void set_next(const char* Kh_next, const char* Vh_next, int at) {
-        k2 = (uint64_t)Kh_next;
-        v2 = (uint64_t)Vh_next;
-        t_switch = at;
-    }
-    __device__ __forceinline__ int select(int t) {   // scalar selects, no branch (see BufStage::select)
-        const bool nx = t >= t_switch;
-        krsrc = descriptor(nx ? k2 : k1, krsrc[2]);
-        vrsrc = descriptor(nx ? v2 : v1, vrsrc[2]);
-        return nx ? t - t_switch : t;
-    }
-    __device__ __forceinline__ void advance() {
-        k1 = k2;
-        v1 = v2;
-        krsrc = descriptor(k1, krsrc[2]);
-        vrsrc = descriptor(v1, vrsrc[2]);
-        t_switch = 0x7fffffff;
-    }
     // The DMA is issued from inline asm: hipcc then keeps no account of it -- issued through the builtin, every ds_read_b64_tr_b16 that
     // follows waits vmcnt(0) for it (the V^T reads of the SAME iteration), because the waitcnt pass cannot tell the ring slots apart.
     // Ordering is by hand instead: wait_all() before the barrier that publishes the tile.  M0 (the LDS destination) is written in the
     // statement that uses it and restored.  The instruction offset stays 0 (it would be added to the LDS address as well); the tile
     // offset goes into the VGPR offset so that the range check covers it.
     __device__ __forceinline__ static void dma16(const u32x4& rsrc, uint32_t lds_byte, int voffset) {
-        if constexpr (SAVE_M0) {
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(voffset), "s"(rsrc), "s"(lds_byte)
-                         : "memory");
-        } else {
-            // (nothing else in these kernels lives in M0: it is written here, in the statement that uses it, and not restored --
-            //  two scalar instructions fewer per piece in the wave's serial instruction stream)
+        // (nothing else in these kernels lives in M0: it is written here, in the statement that uses it, and not restored --
+        //  two scalar instructions fewer per piece in the wave's serial instruction stream; the clobber tells hipcc)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voffset), "s"(rsrc), "s"(lds_byte) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voffset), "s"(rsrc), "s"(lds_byte) : "memory", "m0");
 #pragma clang diagnostic pop
-        }
     }
     // piece #N of tile t (N < LOADS: K, else V) -> ring slot `dst`: key group gi = n / HALVES of this wave, 1-KiB piece j = n % HALVES
     template <int N>
@@ -367,7 +300,6 @@ struct DmaStage {
     __device__ __forceinline__ void wait_all() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     template <int N>
     __device__ __forceinline__ void write(lds_ptr) const {}
-    __device__ __forceinline__ void pin_all() {}
     template <int N = 0> __device__ __forceinline__ void load_all(int t) const { if constexpr (N < NL) { load<N>(t); load_all<N + 1>(t); } }
     __device__ __forceinline__ void load_all_into(int t, lds_ptr slot) { set_dst(slot); load_all(t); }
     __device__ __forceinline__ void write_all(lds_ptr) const {}
@@ -406,7 +338,6 @@ struct HybridStageFp8 {
     }
     template <int N>
     __device__ __forceinline__ void write(lds_ptr slot_base) const { v.template write<N + 1>(slot_base); }
-    __device__ __forceinline__ void pin_all() {}
     __device__ __forceinline__ void wait_all() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __device__ __forceinline__ void load_all(int t) { load<0>(t); load<1>(t); }
     __device__ __forceinline__ void load_all_into(int t, lds_ptr slot) { set_dst(slot); load_all(t); }

@@ -44,17 +44,6 @@ __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma_16x16x32(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
-// TIMING EXPERIMENT ONLY (Opt::dbg bit 3): two 16x16x32 MFMAs on the operands of one 32x32x16 -- same FLOPs, same
-// operand registers, half the accumulator registers written.  The numbers that come out mean nothing.
-__device__ __forceinline__ f32x16 mfma_as_two_16x16x32(bf16x8 a, bf16x8 b, f32x16 c, int which) {
-    f32x4 lo = {c[0], c[1], c[2], c[3]}, hi = {c[4], c[5], c[6], c[7]};
-    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, lo, 0, 0, 0);
-    hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, hi, 0, 0, 0);
-    c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3];
-    c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
-    (void)which;
-    return c;
-}
 __device__ __forceinline__ f32x16 mfma_32x32x16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
@@ -64,17 +53,6 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_fp8(uint64_t a, uint64_t b, f32x
     return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8((long)a, (long)b, c, 0, 0, 0);
 }
 
-// ---- MFMAs with dictated register classes (R = 2 kernels, one wave per SIMD, 512 registers) ------
-// hipcc's own allocation keeps the score accumulators in AGPRs and shuttles them to VGPRs for the
-// softmax (320 v_accvgpr copies per tile).  These inline-asm forms pin: scores + K/V^T/P fragments in
-// VGPRs ("v"), Q fragments and the O accumulators in AGPRs ("a").  hipcc does not see an MFMA inside
-// asm, so it pads no hazards: callers keep MFMA results away from non-MFMA readers (see computers.hip.h)
-// and PAD (s_nop 1) covers a B operand written by a VALU instruction in the previous two issue slots.
-template <bool FIRST>   // FIRST: C = 0 (start of an accumulation chain)
-__device__ __forceinline__ void mfma_qk_asm(f32x16& acc, const u32x4& kfrag, const u32x4& qfrag) {
-    if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(kfrag), "a"(qfrag));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(kfrag), "a"(qfrag));
-}
 // Block-scaled form (MX): v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands and unit scales (E8M0 byte 127 =
 // 2^0) contracts 64 elements per instruction in 16 passes -- twice the rate of the 32x32x16 fp8 form.  A lane
 // supplies 32 bytes per operand; the contraction pairs byte j of lane half h of A with byte j of lane half h of
@@ -84,19 +62,6 @@ __device__ __forceinline__ f32x16 mfma_32x32x64_fp8_unit_scale(u32x4 a_lo, u32x4
     const i32x8 b = {(int)b_lo[0], (int)b_lo[1], (int)b_lo[2], (int)b_lo[3], (int)b_hi[0], (int)b_hi[1], (int)b_hi[2], (int)b_hi[3]};
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
-
-template <bool FIRST>
-__device__ __forceinline__ void mfma_qk_fp8_asm(f32x16& acc, uint64_t a, uint64_t b) {
-    if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_fp8_fp8 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b));
-    else asm volatile("v_mfma_f32_32x32x16_fp8_fp8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
-}
-template <bool PAD>
-__device__ __forceinline__ void mfma_pv_asm(f32x16& o, const bf16x8& vfrag, const bf16x8& pfrag) {
-    if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vfrag), "v"(pfrag));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vfrag), "v"(pfrag));
-}
-// 16-pass MFMA result -> non-MFMA reader: wait out the pipeline (rare paths only: rescale, epilogue)
-__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
 // Row of the 32x32 accumulator tile held in register `reg` of lane half `h`.
 __host__ __device__ constexpr int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }

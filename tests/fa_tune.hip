@@ -60,84 +60,27 @@ static void launch_cfg(const Params& p, int grid) {
         return true;
     }();
     (void)once;
-    if constexpr (K::PERSIST) {
-        // one workgroup per CU (256 on MI355X), or one per unit when there are fewer units than CUs
-        Params q = p;
-        if constexpr (K::QBLK != 256) {   // 128-row units: twice the units, and (ring permitting) two workgroups per CU
-            q.nQ = (p.S + K::QBLK - 1) / K::QBLK;
-            q.units = p.B * p.H * q.nQ;
-            q.cpx = (q.units + 7) / 8;
-        }
-        const int wg_per_cu = (K::QBLK == 128 && 2 * (K::LDS_BYTES + 512) <= 163840) ? 2 : 1;
-        q.jpx = std::min(q.cpx, g_jpx > 0 ? g_jpx : wg_per_cu * g_cus / 8);
-        hipLaunchKernelGGL((fwd_mfma_kernel<K>), dim3(8 * q.jpx), dim3(64 * K::NWAVES), K::LDS_BYTES, nullptr, q);
-    } else {
-        hipLaunchKernelGGL((fwd_mfma_kernel<K>), dim3(grid), dim3(64 * K::NWAVES), K::LDS_BYTES, nullptr, p);
-    }
+    (void)grid;
+    // persistent grid: one workgroup per CU (256 on MI355X), or one per unit when there are fewer units than CUs
+    Params q = p;
+    q.jpx = std::min(q.cpx, g_jpx > 0 ? g_jpx : g_cus / 8);
+    hipLaunchKernelGGL((fwd_mfma_kernel<K>), dim3(8 * q.jpx), dim3(64 * K::NWAVES), K::LDS_BYTES, nullptr, q);
 }
 
-// Every variant is the production configuration (fa::Opt's defaults) with the named fields changed.
+// Every variant is a library configuration, or the production configuration with one knob under study changed.  (The arms of
+// rounds 1 and 2 -- 64-row waves, 4-slot ring, ping-pong phases, unit streaming, packed softmax math, wait grouping, ... -- were
+// measured, rejected and removed; their logs are profiles/r01_tune_*, r02_tune_*.)
 template <int D, bool CAUSAL>
 static std::vector<Variant> make_variants() {
     using T = __bf16;
     std::vector<Variant> v;
-#ifdef FA_TUNE_FOCUS   // a short list for many-round A/B runs of the knobs under study (edit freely)
-    v.push_back({"16x16x32", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1}>>});
-    v.push_back({"16x16x32 vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .m16 = 1}>>});
-    v.push_back({"16x16x32 (again)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.thr = 9, .m16 = 1}>>});
-    v.push_back({"16x16x32 vpre 3 (again)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .thr = 9, .m16 = 1}>>});
-    return v;
-#endif
     v.push_back({"production (16x16x32 non-causal, 32x32x16 causal)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
-    v.push_back({"16x16x32 MFMAs", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1}>>});
-    v.push_back({"32x32x16 MFMAs", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0}>>});
-    v.push_back({"register staging (no LDS-DMA), 16x16x32", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 1, .dma = false}>>});
-    v.push_back({"register staging (no LDS-DMA), 32x32x16", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0, .dma = false}>>});
-#ifdef FA_TUNE_SWEEP
-    v.push_back({"npre 6", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .m16 = CAUSAL ? 0 : -1}>>});
-    v.push_back({"npre 8", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 8, .m16 = CAUSAL ? 0 : -1}>>});
-    v.push_back({"vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .m16 = CAUSAL ? 0 : -1}>>});
-    v.push_back({"vpre 4", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 4, .m16 = CAUSAL ? 0 : -1}>>});
-    v.push_back({"npre 6 vpre 3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3, .m16 = CAUSAL ? 0 : -1}>>});
-    v.push_back({"npre 2 vpre 1", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 2, .vpre = 1, .m16 = CAUSAL ? 0 : -1}>>});
-    v.push_back({"slot order flipped (VALU-first <-> MFMA-first)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = CAUSAL ? 0 : 1, .m16 = CAUSAL ? 0 : -1}>>});
-#endif
-    if constexpr (D == 64) {
-        v.push_back({"4 waves x 32 rows: 128-row units, two workgroups per CU", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.waves = 4, .m16 = CAUSAL ? 0 : -1}>>});
-        v.push_back({"4 waves x 32 rows, the other engine", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.waves = 4, .m16 = CAUSAL ? 1 : 0}>>});
-        v.push_back({"4 waves x 32 rows, register staging", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.waves = 4, .m16 = CAUSAL ? 0 : -1, .dma = false}>>});
-    }
-    v.push_back({"unit streaming (no per-unit prologue)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.stream = 1}>>});
+    v.push_back({"the other engine", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = CAUSAL ? 1 : 0}>>});
     v.push_back({"fp16 weights (FA_FLAG_F16_WEIGHTS)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>});
-    v.push_back({"exact row sums (the LSE instantiation)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.sum_mfma = 0}>>});
-#ifdef FA_TUNE_FULL   // the round-1 arms (rejected by measurement): ~3 more minutes of compile time
-    v.push_back({"waits grouped by 2 (npre4 vpre3)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.vpre = 3, .wg = 2}>>});
-    v.push_back({"waits grouped by 2 (npre6 vpre3)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3, .wg = 2}>>});
-    v.push_back({"waits grouped by 4 (npre8 vpre5)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 8, .vpre = 5, .wg = 4}>>});
-    v.push_back({"4-slot ring, K fragments prefetched across the barrier", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.ring = 4}>>});
-    v.push_back({"early store by waves past the causal diagonal", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.early_store = true}>>});
-    v.push_back({"Q as per-lane 16-byte pieces (no LDS trip)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.coalesced_q = 0}>>});
-    v.push_back({"production + packed fp32 softmax math", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.pk = true}>>});
-    v.push_back({"production + last step without QK", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.skip_last_qk = true}>>});
-    v.push_back({"fp32 O, direct epilogue", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.lds_epilogue32 = false}>>, 4});
-    v.push_back({"fp32 O, LDS epilogue (production)", launch_cfg<ProdCfg<D, CAUSAL, float>>, 4});
-    v.push_back({"production + dot2 row sums", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dot2 = true}>>});
-    v.push_back({"EXPERIMENT no per-tile barrier (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 1}>>});
-    v.push_back({"EXPERIMENT no global loads in loop (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 2}>>});
-    v.push_back({"EXPERIMENT P.V takes constant P (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 4}>>});
-    v.push_back({"EXPERIMENT no barrier + no loads + constant P (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.dbg = 7}>>});
-#endif
-    v.push_back({"32x32x16, QK^T pairs share their Q fragment", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0, .qk_pair_order = true}>>});
-    v.push_back({"EXPERIMENT two 16x16x32 per 32x32x16 (wrong O)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = 0, .dbg = 8}>>});
-    v.push_back({"R=2 asm persistent (experimental)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.r = 2, .asm_mfma = true}>>});
-#ifdef FA_TUNE_FULL
-    v.push_back({"one unit per workgroup (r01 a-j)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.persist = false}>>});
-    v.push_back({"tracked only (persistent)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.optimistic = false}>>});
-    v.push_back({"persistent npre6 vpre3", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.npre = 6, .vpre = 3}>>});
-    v.push_back({"MFMA-first slots (old order)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.valu_first = 0}>>});
-    v.push_back({"one unit per workgroup STAMP", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.stamp = true, .persist = false}>>});
-#endif
+    v.push_back({"exact row sums (the LSE instantiation)", launch_cfg<ProdCfg<D, CAUSAL, T, 2, false, false, true>>});
+    v.push_back({"fp32 O (production)", launch_cfg<ProdCfg<D, CAUSAL, float>>, 4});
     v.push_back({"production STAMP", launch_cfg<ProdCfg<D, CAUSAL, T, 2, true>>});
+    v.push_back({"fp32 O STAMP", launch_cfg<ProdCfg<D, CAUSAL, float, 2, true>>, 4});
     return v;
 }
 
@@ -145,8 +88,6 @@ template <bool CAUSAL>
 static std::vector<Variant> make_variants_fp8() {
     std::vector<Variant> v;
     v.push_back({"fp8 production (MX: QK^T on 32x32x64 f8f6f4, unit scales; K by LDS-DMA)", launch_cfg<ProdCfg<128, CAUSAL, __bf16, 1>>});
-    v.push_back({"fp8, K through registers (no LDS-DMA)", launch_cfg<KernelCfg<128, CAUSAL, __bf16, 1, Opt{.m16 = 0, .dma = false}>>});
-    v.push_back({"fp8 QK^T on the non-scaled 32x32x16 fp8 MFMA", launch_cfg<KernelCfg<128, CAUSAL, __bf16, 1, Opt{.mxqk = 0}>>});
     return v;
 }
 
@@ -220,10 +161,8 @@ int main(int argc, char** argv) {
     if (fp8 && d == 128) vars = causal ? make_variants_fp8<true>() : make_variants_fp8<false>();
     else if (fp8) { fprintf(stderr, "--fp8 needs d = 128\n"); return 2; }
     else if (d == 128) vars = causal ? make_variants<128, true>() : make_variants<128, false>();
-#if defined(FA_TUNE_FULL) || defined(FA_TUNE_D64)
     else if (d == 64) vars = causal ? make_variants<64, true>() : make_variants<64, false>();
-#endif
-    else { fprintf(stderr, "d must be 128 (or 64 in a -DFA_TUNE_D64 / -DFA_TUNE_FULL build)\n"); return 2; }
+    else { fprintf(stderr, "d must be 128 or 64\n"); return 2; }
     if (!only.empty()) {
         std::vector<Variant> sel;
         for (int i : only) if (i >= 0 && i < (int)vars.size()) sel.push_back(vars[i]);

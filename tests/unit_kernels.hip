@@ -243,7 +243,7 @@ static void test_mfma_layouts() {
 template <int D, bool DMA>
 __global__ __launch_bounds__(512) void lds_image_kernel(const uint16_t* K, const uint16_t* V, int S, uint16_t* img, uint16_t* kfr,
                                                         uint16_t* vfr) {
-    using C = KernelCfg<D, false, __bf16, 2, Opt{.m16 = 0, .dma = DMA}>;   // the 32x32x16 engine; DMA: LDS-DMA staging (production)
+    using C = KernelCfg<D, false, __bf16, 2, Opt{.pad = !DMA, .m16 = 0}>;   // the 32x32x16 engine; DMA: LDS-DMA staging (production)
     static_assert(C::DMA == DMA);
     using G = TileGeom<D, 2>;
     using W = WaveCompute<C>;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512) void lds_image_kernel(const uint16_t* K, const
 template <int D, bool DMA>
 static void test_lds_image(const int S = 64) {
     using G = TileGeom<D, 2>;
-    using W = WaveCompute<KernelCfg<D, false, __bf16, 2, Opt{.m16 = 0, .dma = DMA}>>;
+    using W = WaveCompute<KernelCfg<D, false, __bf16, 2, Opt{.pad = !DMA, .m16 = 0}>>;
     std::vector<uint16_t> hk(64 * D, 0), hv(64 * D, 0);   // rows S .. 63 do not exist: expected 0
     for (int i = 0; i < S * D; ++i) { hk[i] = (uint16_t)(i + 1); hv[i] = (uint16_t)(0x8000 + i + 1); }   // "i + 1", V tagged
     uint16_t *dk, *dv, *dimg, *dkf, *dvf;
@@ -336,7 +336,7 @@ static void test_lds_image(const int S = 64) {
 template <int D, bool DMA>
 __global__ __launch_bounds__(512) void lds_image16_kernel(const uint16_t* K, const uint16_t* V, int S, uint16_t* img, uint16_t* kfr,
                                                           uint16_t* vfr) {
-    using C = KernelCfg<D, false, __bf16, 2, Opt{.m16 = 1, .dma = DMA}>;
+    using C = KernelCfg<D, false, __bf16, 2, Opt{.pad = !DMA, .m16 = 1}>;
     static_assert(C::M16 && C::DMA == DMA);
     using G = TileGeom<D, 2>;
     using W = WaveCompute16<C>;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(512) void lds_image16_kernel(const uint16_t* K, con
 template <int D, bool DMA>
 static void test_lds_image16(const int S = 64) {
     using G = TileGeom<D, 2>;
-    using W = WaveCompute16<KernelCfg<D, false, __bf16, 2, Opt{.m16 = 1, .dma = DMA}>>;
+    using W = WaveCompute16<KernelCfg<D, false, __bf16, 2, Opt{.pad = !DMA, .m16 = 1}>>;
     std::vector<uint16_t> hk(64 * D, 0), hv(64 * D, 0);   // rows S .. 63 do not exist: expected 0
     for (int i = 0; i < S * D; ++i) { hk[i] = (uint16_t)(i + 1); hv[i] = (uint16_t)(0x8000 + i + 1); }
     uint16_t *dk, *dv, *dimg, *dkf, *dvf;
@@ -425,7 +425,7 @@ static void test_lds_image16(const int S = 64) {
 // (V is widened to bf16 on its way into LDS: covered end to end by the fp8 parity tests.)
 template <bool DMA>
 __global__ __launch_bounds__(512) void lds_image_fp8_kernel(const uint8_t* K, const uint8_t* V, int S, uint8_t* kfr) {
-    using C = KernelCfg<128, false, __bf16, 1, Opt{.dma = DMA}>;
+    using C = KernelCfg<128, false, __bf16, 1, Opt{.pad = !DMA}>;
     static_assert(C::DMA_K8 == DMA && !C::M16);
     using G = TileGeom<128, 1>;
     using W = WaveCompute<C>;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(512) void lds_image_fp8_kernel(const uint8_t* K, co
 template <bool DMA>
 static void test_lds_image_fp8(const int S = 64) {
     using G = TileGeom<128, 1>;
-    using W = WaveCompute<KernelCfg<128, false, __bf16, 1, Opt{.dma = DMA}>>;
+    using W = WaveCompute<KernelCfg<128, false, __bf16, 1, Opt{.pad = !DMA}>>;
     constexpr int D = 128;
     std::vector<uint8_t> hk(64 * D, 0), hv(S * D, 0);     // rows S .. 63 do not exist: expected 0; e4m3 codes below 0x78 (no NaN / inf patterns)
     for (int i = 0; i < S * D; ++i) hk[i] = (uint8_t)((i * 7 + 1) % 0x77);
