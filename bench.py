@@ -2,24 +2,31 @@
 """bench.py -- forward attention TFLOP/s on MI355X (BASELINE.json metric), one process per GPU.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg2nc|cfg1|cfg3|cfg4]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (one flash_attention launch) over one batch of synthetic
-N(0,1) bf16 tensors already resident in HBM.  Default workload = BASELINE.json configs[2], the
-configuration the metric is quoted on: bf16, B=8, H=16, S=4096, d=128, causal.  With N > 1 every
-rank runs that same per-GPU batch on its own heads (weak scaling: the path shards over batch x head
-with no data-path collective; RCCL carries only the MAX of elapsed times, outside the timed region),
-and the line also carries a `cfg4` sub-record: BASELINE configs[4] (B=64, H=32, S=8192, d=128) with its
-2048 heads split over the N ranks (strong scaling), a few steps.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process (which has not touched the GPU) starts the N ranks
+itself -- a child `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same
+arguments>` -- relays rank 0's single JSON line and exits with the children's status.  Started under torchrun by someone else
+(RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* set) it is one of the ranks.
+
+A "step" is one pass of the hot path (one flash_attention call) over one batch of synthetic N(0,1) bf16 tensors already
+resident in HBM.  Default workload = BASELINE.json configs[2], the configuration the metric is quoted on: bf16, B=8, H=16,
+S=4096, d=128, causal, with fp32 output (the reference's O is float*, kernels/FlashAttention.cuh:61).  With N > 1 every rank
+runs that same per-GPU batch on its own heads (weak scaling: the path shards over batch x head with no data-path collective;
+RCCL carries only the MAX of elapsed times, outside the timed region).  Every line also carries a `cfg4` sub-record: BASELINE
+configs[4] (B=64, H=32, S=8192, d=128) with its 2048 heads split over the N ranks (strong scaling; N = 1 is its anchor), a
+few steps, and a `bf16_out` sub-record: the same workload with bf16 output.
 FLOPs: 4*B*H*S^2*d non-causal, 2*B*H*S^2*d causal (only unmasked work counts) -- SURVEY.md 8(d).
 
 Rank 0 prints ONE JSON line with
-  `roofline`      HIP-event kernel time against the bound that applies to the workload (see bound_for), the HBM traffic
-                  measured by the committed PMC run IF it was taken on the same kernel sources (provenance hash), and
+  `value`         whole-job TFLOP/s from the host clock around exactly K steps between barriers, on a PRIMED device (~100 ms of
+                  the same launches first; `value_unprimed` is the same K steps from a device just out of idle);
+                  `ms_median` / `ms_min`: per-step HIP-event times of those K steps,
+  `roofline`      HIP-event kernel time against the dense MFMA peak of the workload's arithmetic, the HBM traffic measured by
+                  the committed PMC run IF it was taken on the same kernel sources (provenance hash), and
   `cpu_baseline`  (N=1) the oracle's naive fp32 attention timed on the host cores over a bounded sample of THIS run's own
                   tensors, whose result is also the checker for `parity`: max-abs / max-rel error and the fraction of
-                  elements inside the stated tolerance |O-ref| <= 1e-3 + 1e-3|ref|.
+                  elements inside the stated tolerance |O-ref| <= 1e-3 + 1e-3|ref|.  A pass fraction
+                  under the floor (1.0 with fp32 output) sets `output_ok` false and the exit status 3.
 `--dry-run` (CPU, gloo): no kernel is launched and nothing is measured -- the line's STRUCTURE for N ranks (tests).
 """
 from __future__ import annotations
@@ -27,6 +34,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -36,6 +45,7 @@ sys.path.insert(0, os.path.join(ROOT, "profiles"))
 
 PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md)
 METRIC = "fwd attention TFLOP/s/GPU (bf16, seq=4096, d=128) + % MFMA peak"   # BASELINE.json, verbatim
+PROFILE_ROUND = "r03"       # profiles/<round>_hbm_traffic_<workload>.json is where roofline.traffic comes from
 
 WORKLOADS = {
     # name: (B, H, S, d, causal, description)
@@ -45,6 +55,9 @@ WORKLOADS = {
     "cfg4": (64, 32, 8192, 128, False, "BASELINE cfg4: bf16 B=64 H=32 S=8192 d=128, B*H sharded over the ranks"),
     "cfg3": (1, 16, 16384, 128, False, "BASELINE cfg3: fp8 e4m3fn B=1 H=16 S=16384 d=128 non-causal (B, H chosen: unspecified)"),
 }
+# parity.pass_frac_at_1e-3 below this fails the run: every sampled element with fp32 output (the stated tolerance, met by the
+# default weight precisions: include/flash_attention.h); 2-byte outputs add their own rounding (2^-9 relative for bf16)
+PARITY_FLOOR = {"f32": 1.0, "bf16": 0.998}
 
 
 def flops_of(BH, S, d, causal):
@@ -52,32 +65,42 @@ def flops_of(BH, S, d, causal):
 
 
 def bound_for(workload):
-    """(bound, peak TFLOP/s, derivation) of the dominant kernel for a workload.
+    """(bound, peak TFLOP/s, derivation, issue_bound) of the dominant kernel for a workload.
 
-    The SIMD's vector-issue port serves BOTH waves of a SIMD one instruction at a time: an MFMA holds it 8 cycles, v_exp_f32 8,
-    v_fma_f32 / v_cvt_pk 4 (MI355X_MICROARCH.md 'vector-instruction ISSUE cost'; tests/micro/valu_rates).  Per wave and 64-key
-    tile the 16x16x32 engine issues D/2 + 4 MFMAs and 32 x (fma + exp) + 16 cvt_pk; the MFMA pipe is busy 16 cycles per
-    MFMA.  d = 128: 68 MFMAs -> 1088 pipe cycles against 992 vector-issue cycles: the pipe binds -> "mfma", nominal peak.
-    d = 64: 36 MFMAs -> 576 pipe cycles against 736 vector-issue cycles: vector issue binds -> "valu", and the peak is the
-    MFMA peak scaled by useful-MFMA pipe cycles / vector-issue cycles = 2516.6 * 512 / 736.
-    fp8 (cfg3): QK^T on the block-scaled MX MFMA at twice the bf16 rate, P.V at the bf16 rate: time-weighted mix."""
+    `peak` is the dense MFMA peak of the arithmetic the kernel runs -- the metric's own denominator ("% MFMA peak"): 2516.6 for
+    bf16; for fp8 inputs (cfg3) QK^T runs on the block-scaled MX MFMA at twice the bf16 rate and P.V at the bf16 rate, so the
+    time-weighted mix 1 / (0.5 / 5033.2 + 0.5 / 2516.6).
+    `issue_bound` (a labelled extra, never the denominator of `frac`): the SIMD's vector-issue port serves BOTH waves of a SIMD
+    one instruction at a time -- an MFMA holds it 8 cycles, v_exp_f32 8, v_fma_f32 / v_add_f32 / v_cvt_pk 4
+    (MI355X_MICROARCH.md 'vector-instruction ISSUE cost') -- so per wave and 64-key tile the engine the library launches issues
+      32x32x16 (causal bf16):      d/4 MFMAs of 32 pipe cycles + 32 x (fma + exp + add) + 16 cvt_pk
+      16x16x32 (non-causal bf16):  d/2 + 4 MFMAs of 16 pipe cycles (4 of them the row sums) + 32 x (fma + exp) + 16 cvt_pk
+    and where the issue cycles exceed the MFMA pipe cycles, vector issue and not the pipe is the ceiling of that engine."""
     if workload == "cfg3":
-        return "mfma", 1.0 / (0.5 / (2 * PEAK_BF16_TFLOPS) + 0.5 / PEAK_BF16_TFLOPS), "0.5 of the FLOPs at the MX fp8 rate (2x), 0.5 at the bf16 rate"
-    d = WORKLOADS[workload][3]
-    n_mfma = d // 2 + 4              # QK^T: 4 key groups x d/32 k-steps x 2 query groups; P.V: d/16 x 2 x 2; 4 row-sum MFMAs
-    pipe, issue, useful = 16 * n_mfma, 8 * n_mfma + 32 * (4 + 8) + 16 * 4, 16 * (n_mfma - 4)
-    if issue > pipe:
-        return "valu", PEAK_BF16_TFLOPS * useful / issue, f"vector issue {issue} > MFMA pipe {pipe} cycles per wave-tile; peak = MFMA peak x {useful}/{issue}"
-    return "mfma", PEAK_BF16_TFLOPS, f"MFMA pipe {pipe} >= vector issue {issue} cycles per wave-tile; nominal dense bf16 peak"
+        return ("mfma", 1.0 / (0.5 / (2 * PEAK_BF16_TFLOPS) + 0.5 / PEAK_BF16_TFLOPS),
+                "0.5 of the FLOPs at the MX fp8 rate (2x), 0.5 at the bf16 rate", None)
+    d, causal = WORKLOADS[workload][3], WORKLOADS[workload][4]
+    if causal:      # 32x32x16 engine, fp32 row sums by v_add_f32
+        n_mfma, cyc = d // 4, 32
+        pipe, useful, issue = cyc * n_mfma, cyc * n_mfma, 8 * n_mfma + 32 * (4 + 8 + 4) + 16 * 4
+        eng = "32x32x16"
+    else:           # 16x16x32 engine, row sums by 4 ONES.P^T MFMAs
+        n_mfma, cyc = d // 2 + 4, 16
+        pipe, useful, issue = cyc * n_mfma, cyc * (n_mfma - 4), 8 * n_mfma + 32 * (4 + 8) + 16 * 4
+        eng = "16x16x32"
+    ib = {"engine": eng, "mfma_pipe_cycles_per_wave_tile": pipe, "vector_issue_cycles_per_wave_tile": issue,
+          "ceiling_tflops": round(PEAK_BF16_TFLOPS * useful / max(pipe, issue), 1),
+          "binds": "vector issue" if issue > pipe else "mfma pipe"}
+    return "mfma", PEAK_BF16_TFLOPS, "nominal dense bf16 MFMA peak: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz", ib
 
 
 def measured_traffic(workload):
     """HBM bytes per launch from the committed PMC run of this same command (separate FETCH_SIZE / WRITE_SIZE passes,
-    FETCH_SIZE doubled as the gfx950 guide prescribes) -- profiles/r02_hbm_traffic_<workload>.json -- but ONLY if that run
+    FETCH_SIZE doubled as the gfx950 guide prescribes) -- profiles/<round>_hbm_traffic_<workload>.json -- but ONLY if that run
     was taken on the kernel sources that are built now (sha256 over csrc/, profiles/provenance.py): a measurement of
     other code is not this run's traffic.  Returns (bytes or None, provenance dict)."""
     import provenance
-    path = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_{workload}.json")
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_hbm_traffic_{workload}.json")
     now = provenance.csrc_sha256()
     try:
         with open(path) as f:
@@ -99,7 +122,6 @@ def power_limited_ceiling():
     per-MFMA instruction mix (softmax VALU ops + K / V^T LDS reads), both on RANDOM bf16 operands, pipe >= 90 %
     busy -- the chip then holds 1.3-1.7 GHz, not the 2.4 GHz behind the 2516.6 TFLOP/s nominal peak.  A separate
     child process started BEFORE this process touches the GPU; None if the microbenchmark is not built."""
-    import subprocess
     exe = os.path.join(ROOT, "tests", "micro", "simd_mix")
     if not os.path.exists(exe):
         return None
@@ -139,11 +161,11 @@ def cpu_baseline_and_parity(Q, K, V, O, S, d, causal, budget_s=12.0):
             "sample": f"the last {nh} head(s) of this run's tensors (S={S}, d={d}, causal={causal}), fp32 naive attention, "
                       f"{t:.2f} s wall, OpenMP over query rows"}
     par = parity_report(got, ref)
-    par["checked"] = f"GPU output of the same {nh} head(s) against the oracle's result on the same (rounded) inputs"
+    par["checked"] = f"GPU output of the same {nh} head(s) (whole heads, every row) against the oracle's result on the same (rounded) inputs"
     return base, par
 
 
-def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps, warmup, dry, want_parity):
+def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps, warmup, dry, want_parity, out_dtype, prime=True):
     """One workload on this rank; returns the rank-0 record (None elsewhere)."""
     B, H, S, d, causal, desc = WORKLOADS[workload]
     if workload == "cfg4":           # fixed total problem, B*H split over the ranks (strong scaling)
@@ -152,14 +174,14 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
     else:                            # same batch on every rank (weak scaling)
         heads_local, scaling, total_heads = B * H, "weak", B * H * world
     esz = 1 if workload == "cfg3" else 2
-    osz = 2 if args.out_dtype == "bf16" else 4
+    osz = 2 if out_dtype == "bf16" else 4
     Q = K = V = O = None
     if not dry:
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         shape = (heads_local, 1, S, d)   # the rank's slab as a dense [heads,1,S,d] tensor
         in_dtype = torch.float8_e4m3fn if workload == "cfg3" else torch.bfloat16
         Q, K, V = (torch.randn(shape, generator=g, device=dev, dtype=torch.float32).to(in_dtype) for _ in range(3))
-        O = torch.empty(shape, device=dev, dtype=torch.bfloat16 if args.out_dtype == "bf16" else torch.float32)
+        O = torch.empty(shape, device=dev, dtype=torch.bfloat16 if out_dtype == "bf16" else torch.float32)
     scale = 1.0 / d ** 0.5
 
     def step():
@@ -173,27 +195,31 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
             torch.cuda.synchronize()
 
     def timed(n):
-        """n steps between barriers; (host seconds, HIP-event ms per step on the launch stream)"""
+        """n steps between barriers; (host seconds, per-step HIP-event ms on the launch stream)"""
         sync()
         if world > 1:
             dist.barrier()
         sync()
-        ev0 = ev1 = None
-        if not dry:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] if not dry else None
+        per = []
         t0 = time.perf_counter()
-        if ev0:
-            ev0.record()             # same stream the kernel is launched on (torch's current stream)
-        for _ in range(n):
+        for i in range(n):
+            if ev:
+                ev[i].record()       # same stream the kernel is launched on (torch's current stream)
+            ts = time.perf_counter()
             step()
-        if ev1:
-            ev1.record()
+            if not ev:
+                per.append((time.perf_counter() - ts) * 1e3)
+        if ev:
+            ev[n].record()
         sync()
         if world > 1:
             dist.barrier()
         sync()
         el = time.perf_counter() - t0
-        return el, (ev0.elapsed_time(ev1) / n if ev0 else el / n * 1e3)
+        if ev:
+            per = [ev[i].elapsed_time(ev[i + 1]) for i in range(n)]
+        return el, per
 
     # first touch (LDS limit raised, code object loaded), then the UNPRIMED figure: the same K steps from a device that has
     # just come out of idle -- what a caller sees on its first few calls (clock ramp; reported beside `value`, never as it)
@@ -201,21 +227,25 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
     el_cold, _ = timed(steps)
     # Device priming (setup, untimed, before the W warmup steps): a GPU coming out of idle needs tens of milliseconds of
     # work before its power state and clocks settle.  ~100 ms of the same launches, at most 3000.
-    t_p = time.perf_counter(); step(); step(); sync()
-    t_step = max((time.perf_counter() - t_p) / 2, 1e-6)
-    for _ in range(max(0, min(3000, int(0.1 / t_step)))):
-        step()
-    sync()
+    if prime:
+        t_p = time.perf_counter(); step(); step(); sync()
+        t_step = max((time.perf_counter() - t_p) / 2, 1e-6)
+        for _ in range(max(0, min(3000, int(0.1 / t_step)))):
+            step()
+        sync()
     for _ in range(warmup):
         step()
-    elapsed, kernel_ms = timed(steps)
+    elapsed, per_step = timed(steps)
     elapsed = shard.reduce_max(elapsed)
     el_cold = shard.reduce_max(el_cold)
+    kernel_ms = sum(per_step) / len(per_step)
     kernel_ms_max = shard.reduce_max(kernel_ms)
+    ms_median = shard.reduce_max(statistics.median(per_step))
+    ms_min = shard.reduce_max(min(per_step))
 
     ok = True
     if not dry:                      # sanity: the output is finite and row 0 of a causal head equals V[0]
-        ok = bool(torch.isfinite(O.float()).all())
+        ok = bool(torch.isfinite(O.float()).all()) if heads_local <= 256 else bool(torch.isfinite(O[:64].float()).all() and torch.isfinite(O[-64:].float()).all())
         if causal:
             ok = ok and bool(torch.allclose(O[:, :, 0].float(), V[:, :, 0].float(), rtol=1e-2, atol=1e-2))
     ok_all = shard.reduce_sum(0.0 if ok else 1.0) == 0.0
@@ -225,8 +255,8 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
     ms_per_step = elapsed / steps * 1e3
     value = flops_of(total_heads, S, d, causal) / (ms_per_step * 1e-3) / 1e12
     achieved = flops_of(heads_local, S, d, causal) / (kernel_ms_max * 1e-3) / 1e12
-    bound, peak, why = bound_for(workload)
-    traffic, prov = measured_traffic(workload) if world == 1 else (None, None)
+    bound, peak, why, issue_bound = bound_for(workload)
+    traffic, prov = measured_traffic(workload) if world == 1 and out_dtype == args.out_dtype else (None, None)
     algo_bytes = heads_local * S * d * (3 * esz + osz)
     rec = {
         "metric": METRIC if workload.startswith("cfg2") else f"fwd attention TFLOP/s/GPU ({desc}) + % MFMA peak",
@@ -235,19 +265,25 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
         "scaling": scaling, "vs_baseline": None, "dtype": "fp8_e4m3fn" if workload == "cfg3" else "bf16",
         "data": "synthetic",
         "config": {"workload": desc, "B": B, "H": H, "S": S, "d": d, "causal": causal,
-                   "out_dtype": args.out_dtype, "heads_per_gpu": heads_local,
+                   "out_dtype": out_dtype, "heads_per_gpu": heads_local,
+                   "softmax_weights": "library default: fp16 on the query rows that see fewer than 1024 keys, bf16 elsewhere" if esz == 2 else "bf16",
                    "flop_convention": "2*B*H*S^2*d causal / 4*B*H*S^2*d non-causal",
                    "parallelism": f"batch x head shard over {world} GPU(s), no data-path collective"},
+        "rccl_ranks": world,
         "value_per_gpu": round(value / world, 2),
         "pct_of_bf16_mfma_peak": round(100.0 * value / (PEAK_BF16_TFLOPS * world), 2),
+        # per-step HIP-event times of the K timed steps (median and min beside the mean that defines `value`)
+        "ms_median": round(ms_median, 5), "ms_min": round(ms_min, 5),
+        "value_at_ms_median": round(flops_of(total_heads, S, d, causal) / (ms_median * 1e-3) / 1e12, 2),
+        "device_primed": bool(prime),
         # the same K steps timed BEFORE the ~100 ms priming loop (device just out of idle): not the metric, the caveat
         "value_unprimed": round(flops_of(total_heads, S, d, causal) / (el_cold / steps) / 1e12, 2),
         # causal FLOPs count only the unmasked half; the full-count figure alongside, labelled
         "value_if_masked_half_counted_too": round(value * (2.0 if causal else 1.0), 2),
         "output_ok": ok_all,
         "roofline": {"bound": bound, "achieved": round(achieved, 2), "peak": round(peak, 1),
-                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "bound_derivation": why,
-                     "frac_of_nominal_bf16_mfma_peak": round(achieved / PEAK_BF16_TFLOPS, 4),
+                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "peak_derivation": why,
+                     "issue_bound": issue_bound,
                      "traffic": traffic, "traffic_provenance": prov,
                      "kernel": "fa::fwd_mfma_kernel", "kernel_ms": round(kernel_ms_max, 5),
                      "algorithmic_hbm_bytes": algo_bytes,
@@ -257,7 +293,26 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
         rec["dry_run"] = True
     if want_parity and not dry:
         rec["cpu_baseline"], rec["parity"] = cpu_baseline_and_parity(Q, K, V, O, S, d, causal)
+        floor = PARITY_FLOOR[out_dtype]
+        rec["parity"]["floor"] = floor
+        if rec["parity"]["pass_frac_at_1e-3"] < floor:
+            rec["output_ok"] = False
     return rec
+
+
+def launch_ranks(n, argv):
+    """Parent of an N-rank run: start N fresh processes (one per GPU) through torch.distributed.run, relay their output, return
+    their exit status.  This process never initialises the GPU (no exec from a process that has)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py")] + argv
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -268,14 +323,23 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the power-limited-ceiling microbenchmark")
-    ap.add_argument("--no-cfg4", action="store_true", help="N > 1: skip the cfg4 strong-scaling sub-record")
-    ap.add_argument("--out-dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the cfg4 strong-scaling sub-record")
+    ap.add_argument("--no-bf16-out", action="store_true", help="skip the bf16-output sub-record")
+    ap.add_argument("--out-dtype", default="f32", choices=["bf16", "f32"],
+                    help="element type of O; f32 = the reference's float* O (kernels/FlashAttention.cuh:61)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: no launches, no measurements -- the line's structure only")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py with --gpus equal to the number of ranks")
 
     # The ceiling microbenchmark is a separate GPU program: run it as a child BEFORE this process touches the GPU
     # (no exec from a process that has initialised HIP).  Single-GPU runs only.
@@ -301,27 +365,41 @@ def main():
         if world > 1:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ranks = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
 
     line = run_workload(fa, shard, torch, dist, args, args.workload, world, rank, dev, args.steps, args.warmup, args.dry_run,
-                        want_parity=world == 1 and not args.no_cpu_baseline)
-    if rank == 0 and ceil:
-        a = line["roofline"]["achieved"]
-        line["roofline"]["power_limited"] = dict(
-            ceil, frac_of_mfma_only=round(a / ceil["mfma_only_random_bf16_tflops"], 4),
-            frac_of_attention_mix=round(a / ceil["attention_mix_random_bf16_tflops"], 4))
-    # N > 1: BASELINE configs[4] itself, its 2048 heads split over the ranks (the driver never passes --workload cfg4)
-    if world > 1 and not args.no_cfg4 and args.workload != "cfg4":
-        sub = run_workload(fa, shard, torch, dist, args, "cfg4", world, rank, dev, max(2, min(5, args.steps)), 1, args.dry_run, False)
+                        want_parity=world == 1 and not args.no_cpu_baseline, out_dtype=args.out_dtype)
+    if rank == 0:
+        line["rccl_ranks"] = ranks
+        if ceil:
+            a = line["roofline"]["achieved"]
+            line["roofline"]["power_limited"] = dict(
+                ceil, frac_of_mfma_only=round(a / ceil["mfma_only_random_bf16_tflops"], 4),
+                frac_of_attention_mix=round(a / ceil["attention_mix_random_bf16_tflops"], 4))
+    few = max(2, min(5, args.steps))
+    # the same workload with bf16 output (half the output bytes; its rounding alone exceeds the stated tolerance for |O| > 1)
+    if not args.no_bf16_out and args.out_dtype != "bf16" and args.workload != "cfg4":
+        sub = run_workload(fa, shard, torch, dist, args, args.workload, world, rank, dev, args.steps, args.warmup, args.dry_run, False, "bf16", prime=False)
         if rank == 0:
-            line["cfg4"] = {k: sub[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config",
+            line["bf16_out"] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "ms_median", "ms_min", "output_ok")}
+            line["bf16_out"]["roofline"] = {k: sub["roofline"][k] for k in ("achieved", "peak", "frac", "kernel_ms")}
+    # BASELINE configs[4] itself, its 2048 heads split over the ranks (the driver never passes --workload cfg4); N = 1: the anchor
+    if not args.no_cfg4 and args.workload != "cfg4":
+        sub = run_workload(fa, shard, torch, dist, args, "cfg4", world, rank, dev, few, 1, args.dry_run, False, args.out_dtype, prime=False)
+        if rank == 0:
+            line["cfg4"] = {k: sub[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_median", "ms_min", "scaling", "config",
                                                  "value_per_gpu", "pct_of_bf16_mfma_peak", "output_ok")}
             line["cfg4"]["roofline"] = {k: sub["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms")}
+    rc = 0
     if rank == 0:
+        if not line["output_ok"]:
+            rc = 3
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -25,11 +25,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libflash_attention.so")
 
 FA_DTYPE_F32, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3, FA_DTYPE_F16 = 0, 1, 2, 3
-FA_FLAG_F16_WEIGHTS = 1     # flash_attention_ex: softmax weights rounded to fp16 instead of bf16 (bf16 inputs, d = 64 / 128)
+FA_FLAG_F16_WEIGHTS = 1     # flash_attention_ex: softmax weights rounded to fp16 on every row (bf16 inputs, d = 64 / 128)
+FA_FLAG_BF16_WEIGHTS = 2    # ... to bf16 on every row; flags = 0: fp16 on the rows that see fewer than FA_EARLY_KEYS keys, bf16 elsewhere
+FA_EARLY_KEYS = 1024
 
 # every symbol include/flash_attention.h declares
 EXPORTS = ("flash_attention", "flash_attention_strided", "flash_attention_lse", "flash_attention_cross", "flash_attention_ex", "flash_attention_weights", "flash_attention_shard_range", "flash_attention_sharded",
-           "flash_attention_plan",
+           "flash_attention_plan", "flash_attention_plan_ex",
            "flash_attention_error_string", "flash_attention_version")
 
 
@@ -41,6 +43,10 @@ class FaLaunchPlan(ctypes.Structure):
     _fields_ = [("q_block_rows", ctypes.c_int), ("kv_block_rows", ctypes.c_int),
                 ("threads", ctypes.c_int), ("grid", ctypes.c_int), ("lds_bytes", ctypes.c_int),
                 ("kernel_id", ctypes.c_int)]
+
+
+class FaLaunchPlanEx(ctypes.Structure):
+    _fields_ = [("launch", FaLaunchPlan), ("q_blocks", ctypes.c_int), ("first_q_block", ctypes.c_int)]
 
 
 class FlashAttentionError(RuntimeError):
@@ -81,6 +87,9 @@ def lib() -> ctypes.CDLL:
         L.flash_attention_sharded.restype = i
         L.flash_attention_plan.argtypes = [i, i, i, i, b, i, i, ctypes.POINTER(FaLaunchPlan)]
         L.flash_attention_plan.restype = i
+        px = ctypes.POINTER(FaLaunchPlanEx)
+        L.flash_attention_plan_ex.argtypes = [i, i, i, i, i, b, i, i, ctypes.c_uint, px, px]
+        L.flash_attention_plan_ex.restype = i
         L.flash_attention_error_string.argtypes = [i]
         L.flash_attention_error_string.restype = ctypes.c_char_p
         L.flash_attention_version.argtypes = []
@@ -136,6 +145,15 @@ def plan(batchSize, numHeads, seqLen, dHead, is_causal=False, dtype=FA_DTYPE_BF1
     return {k: getattr(p, k) for k, _ in FaLaunchPlan._fields_}
 
 
+def plan_ex(batchSize, numHeads, seqLenQ, seqLenK, dHead, is_causal=False, dtype=FA_DTYPE_BF16, o_dtype=FA_DTYPE_F32, flags=0):
+    """The launches a flash_attention_ex() call makes: (early, main) dicts; a launch that does not happen has q_blocks = 0."""
+    e, m = FaLaunchPlanEx(), FaLaunchPlanEx()
+    _check(lib().flash_attention_plan_ex(batchSize, numHeads, seqLenQ, seqLenK, dHead, bool(is_causal), dtype, o_dtype, flags,
+                                         ctypes.byref(e), ctypes.byref(m)))
+    conv = lambda x: dict({k: getattr(x.launch, k) for k, _ in FaLaunchPlan._fields_}, q_blocks=x.q_blocks, first_q_block=x.first_q_block)
+    return conv(e), conv(m)
+
+
 def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None, stream=None, return_lse=False, weights_dtype=None):
     """O = softmax(scale * Q K^T [+ causal mask]) V on [B, H, S, d] device tensors.
 
@@ -146,8 +164,9 @@ def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None
     API, kernels/FlashAttention.cuh:23); the causal mask stays ``k > q`` on absolute indices.
     Asynchronous on ``stream`` (default: torch's current stream).  Returns O, or ``(O, LSE)`` with
     ``return_lse=True`` (LSE: fp32 [B, H, S], natural-log sum of exp(scale * scores) over the visible keys).
-    ``weights_dtype=torch.float16`` (bf16 inputs, d = 64 or 128): the precision option FA_FLAG_F16_WEIGHTS of
-    flash_attention_ex -- softmax weights rounded to fp16 instead of bf16 before P.V.
+    ``weights_dtype`` (bf16 inputs): None = the library default (fp16 softmax weights on the rows that see fewer than
+    FA_EARLY_KEYS keys, bf16 weights elsewhere); ``torch.float16`` = FA_FLAG_F16_WEIGHTS (fp16 weights on every row; d = 64
+    or 128); ``torch.bfloat16`` = FA_FLAG_BF16_WEIGHTS (bf16 weights on every row: the fastest form).
     """
     import torch
     if not (Q.is_cuda and K.is_cuda and V.is_cuda):
@@ -172,7 +191,9 @@ def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None
     if weights_dtype is not None:
         if weights_dtype == torch.float16:
             flags |= FA_FLAG_F16_WEIGHTS
-        elif weights_dtype != torch.bfloat16:
+        elif weights_dtype == torch.bfloat16:
+            flags |= FA_FLAG_BF16_WEIGHTS
+        else:
             raise TypeError("weights_dtype must be torch.float16 or torch.bfloat16")
     with torch.cuda.device(Q.device):
         if flags:

@@ -85,6 +85,20 @@ static int device_cus() {
     return n;
 }
 
+// bf16 inputs: how many leading query blocks of every head run the fp16-weights kernel (the rest: the bf16-weights kernel).
+// bf16 weights carry 2^-9 of relative rounding error each; summed over a row's keys it averages out, but a row that sees few
+// keys keeps most of it: at FA_EARLY_KEYS = 1024 visible keys the worst element error measured over 40 random heads is 0.74 of
+// the stated tolerance 1e-3 + 1e-3|ref| (0.90 at 256, 1.33 at 64: those rows miss it).  Default: a row that can see fewer than
+// FA_EARLY_KEYS keys -- under the causal mask the rows q < FA_EARLY_KEYS, and every row when seqLenK < FA_EARLY_KEYS -- gets
+// fp16 weights (11 significant bits; 8 x smaller errors), whole query blocks at a time.
+static int early_q_blocks(int S, int Sk, int d, bool causal, unsigned flags, int q_block_rows) {
+    const int nQ = getNumCta(S, q_block_rows);
+    if (!(d == 64 || d == 128) || (flags & FA_FLAG_BF16_WEIGHTS)) return 0;   // (padded head dimensions have no fp16-weights kernel)
+    if (flags & FA_FLAG_F16_WEIGHTS) return nQ;
+    if (Sk < FA_EARLY_KEYS) return nQ;
+    return causal ? std::min(nQ, FA_EARLY_KEYS / q_block_rows) : 0;
+}
+
 static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_dtype, float scale,
                      fa_launch_plan* plan) {
     // bf16: d in {64,128} natively; any other multiple of 8 up to 128 runs the next larger instantiation with its
@@ -161,9 +175,11 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
                const fa_strides* sK, const fa_strides* sV, const fa_strides* sO, void* stream, unsigned flags = 0) {
     int rc = validate(Q, K, V, O, B, H, S, d, scale, dtype, o_dtype);
     if (rc != FA_OK) return rc;
-    if (flags & ~(unsigned)FA_FLAG_F16_WEIGHTS) return FA_ERR_BAD_FLAGS;
-    // the fp16-weights option exists for bf16 inputs at the natively instantiated head dimensions
+    if (flags & ~(unsigned)(FA_FLAG_F16_WEIGHTS | FA_FLAG_BF16_WEIGHTS)) return FA_ERR_BAD_FLAGS;
+    if ((flags & FA_FLAG_F16_WEIGHTS) && (flags & FA_FLAG_BF16_WEIGHTS)) return FA_ERR_BAD_FLAGS;
+    // the fp16-weights kernels exist for bf16 inputs at the natively instantiated head dimensions
     if ((flags & FA_FLAG_F16_WEIGHTS) && !(dtype == FA_DTYPE_BF16 && (d == 64 || d == 128) && scale > 0.f)) return FA_ERR_BAD_FLAGS;
+    if ((flags & FA_FLAG_BF16_WEIGHTS) && dtype != FA_DTYPE_BF16) return FA_ERR_BAD_FLAGS;
     if (Sk <= 0 || Sk > (1 << 24)) return FA_ERR_BAD_SHAPE;
     if (lse && !aligned16(lse)) return FA_ERR_MISALIGNED;
     const int esz = elem_size(dtype), osz = elem_size(o_dtype);
@@ -179,26 +195,42 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
     }
     Params p;
     fill_params(p, Q, K, V, O, lse, B, H, S, Sk, d, scale, sQ, sK, sV, sO);
-    p.nQ = getNumCta(S, plan.q_block_rows);
-    if ((int64_t)B * H * p.nQ > INT32_MAX / 2) return FA_ERR_BAD_SHAPE;   // unit indices are 32-bit
-    p.units = B * H * p.nQ;
-    p.cpx = (p.units + 7) / 8;
-    p.jpx = plan.grid / 8;
+    const int nQ_total = getNumCta(S, plan.q_block_rows);
+    if ((int64_t)B * H * nQ_total > INT32_MAX / 2) return FA_ERR_BAD_SHAPE;   // unit indices are 32-bit
     p.dbg = nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e;
+    // One launch covers the query blocks [qb0, qb0 + nq) of every head.
+    auto set_range = [&](int qb0, int nq, bool persistent) {
+        p.qb0 = qb0;
+        p.nQ = nq;
+        p.units = B * H * nq;
+        p.cpx = (p.units + 7) / 8;
+        if (persistent) plan.grid = 8 * std::min(p.cpx, device_cus() / 8);   // one workgroup per CU, or per unit when there are fewer
+        else plan.grid = 8 * p.cpx;
+        p.jpx = plan.grid / 8;
+    };
+    hipError_t e = hipSuccess;
     if (plan.kernel_id == 3) {          // fp32 inputs: exact-fp32 MFMA kernel at D = 128 / 64 (narrower rows zero-padded)
+        set_range(0, nQ_total, false);
         e = d > 64 ? launch_f32_d128(p, plan, causal, d != 128, o_dtype, st) : launch_f32_d64(p, plan, causal, d != 64, o_dtype, st);
     } else if (plan.kernel_id == 2) {   // fp8 e4m3fn inputs
+        set_range(0, nQ_total, true);
         e = launch_fp8_d128(p, plan, causal, d != 128, o_dtype, st);
-    } else if (plan.kernel_id == 1 && (flags & FA_FLAG_F16_WEIGHTS)) {
-        e = launch_bf16_p16(p, plan, causal, d, o_dtype, st);
     } else if (plan.kernel_id == 1) {   // bf16 inputs
-        e = d > 64 ? launch_bf16_d128(p, plan, causal, d != 128, o_dtype, st) : launch_bf16_d64(p, plan, causal, d != 64, o_dtype, st);
-    } else if (dtype == FA_DTYPE_F32) {
-        e = launch_generic<float>(p, plan, d, causal, o_dtype, st);
+        // Which query blocks take fp16 softmax weights (early_q_blocks): all with FA_FLAG_F16_WEIGHTS, none with
+        // FA_FLAG_BF16_WEIGHTS, by default the rows that see few keys.  Two launches on the same stream, disjoint output rows.
+        const int hp = early_q_blocks(S, Sk, d, causal, flags, plan.q_block_rows);
+        if (hp > 0) {
+            set_range(0, hp, true);
+            e = launch_bf16_p16(p, plan, causal, d, o_dtype, st);
+        }
+        if (e == hipSuccess && hp < nQ_total) {
+            set_range(hp, nQ_total - hp, true);
+            e = d > 64 ? launch_bf16_d128(p, plan, causal, d != 128, o_dtype, st) : launch_bf16_d64(p, plan, causal, d != 64, o_dtype, st);
+        }
     } else {
-        e = launch_generic<__bf16>(p, plan, d, causal, o_dtype, st);
+        set_range(0, nQ_total, false);
+        e = dtype == FA_DTYPE_F32 ? launch_generic<float>(p, plan, d, causal, o_dtype, st) : launch_generic<__bf16>(p, plan, d, causal, o_dtype, st);
     }
     return (int)e;
 }
@@ -324,6 +356,33 @@ int flash_attention_plan(int batchSize, int numHeads, int seqLen, int dHead, boo
     return fa::make_plan(batchSize, numHeads, seqLen, dHead, is_causal, dtype, o_dtype, 1.0f, plan);
 }
 
+int flash_attention_plan_ex(int batchSize, int numHeads, int seqLenQ, int seqLenK, int dHead, bool is_causal, int dtype,
+                            int o_dtype, unsigned flags, fa_launch_plan_ex* early, fa_launch_plan_ex* main_) {
+    fa_launch_plan base;
+    const int rc = flash_attention_plan(batchSize, numHeads, seqLenQ, dHead, is_causal, dtype, o_dtype, &base);
+    if (rc != FA_OK) return rc;
+    if (seqLenK <= 0) return FA_ERR_BAD_SHAPE;
+    if (flags & ~(unsigned)(FA_FLAG_F16_WEIGHTS | FA_FLAG_BF16_WEIGHTS)) return FA_ERR_BAD_FLAGS;
+    if ((flags & FA_FLAG_F16_WEIGHTS) && ((flags & FA_FLAG_BF16_WEIGHTS) || !(dtype == FA_DTYPE_BF16 && (dHead == 64 || dHead == 128)))) return FA_ERR_BAD_FLAGS;
+    if ((flags & FA_FLAG_BF16_WEIGHTS) && dtype != FA_DTYPE_BF16) return FA_ERR_BAD_FLAGS;
+    const int nQ = getNumCta(seqLenQ, base.q_block_rows);
+    const int hp = base.kernel_id == 1 ? fa::early_q_blocks(seqLenQ, seqLenK, dHead, is_causal, flags, base.q_block_rows) : 0;
+    auto fill = [&](fa_launch_plan_ex* out, int qb0, int nq, bool p16) {
+        if (!out) return;
+        out->launch = base;
+        out->first_q_block = qb0;
+        out->q_blocks = nq;
+        const int64_t units = (int64_t)batchSize * numHeads * nq;
+        if (nq == 0) out->launch.grid = 0;
+        else if (base.kernel_id == 1 || base.kernel_id == 2) out->launch.grid = (int)(8 * std::min<int64_t>((units + 7) / 8, fa::device_cus() / 8));
+        else out->launch.grid = (int)(8 * ((units + 7) / 8));
+        if (p16) out->launch.lds_bytes = fa::bf16_p16_lds_bytes(is_causal, dHead, o_dtype);
+    };
+    fill(early, 0, hp, true);
+    fill(main_, hp, nQ - hp, false);
+    return FA_OK;
+}
+
 const char* flash_attention_error_string(int code) {
     switch (code) {
         case FA_OK: return "success";
@@ -333,7 +392,7 @@ const char* flash_attention_error_string(int code) {
         case FA_ERR_UNSUPPORTED_DHEAD: return "unsupported dHead for this dtype";
         case FA_ERR_UNSUPPORTED_DTYPE: return "unsupported dtype / o_dtype";
         case FA_ERR_BAD_SCALE: return "scale is not finite (fp8 inputs: not positive)";
-        case FA_ERR_BAD_FLAGS: return "unknown flag, or a flag that does not apply to this dtype / dHead";
+        case FA_ERR_BAD_FLAGS: return "unknown or contradictory flags, or a flag that does not apply to this dtype / dHead";
         case FA_ERR_BAD_STRIDE: return "bad or misaligned stride";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown flash_attention error";
     }

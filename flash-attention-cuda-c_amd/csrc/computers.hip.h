@@ -453,6 +453,18 @@ struct WaveCompute {
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): only this wave's own ds_writes have to land
         constexpr int ROWS_PER_INST = 64 / CHUNKS;                          // 4 (D=128) or 8 (D=64)
         const int rr = lane / CHUNKS, cc = lane % CHUNKS;
+        if (!C::PAD && row0 + 32 * R <= S) {   // (wave-uniform) every row of the wave exists: reads in flight together, plain stores
+            u32x4 v[32 * R / ROWS_PER_INST];
+#pragma unroll
+            for (int i = 0; i < 32 * R / ROWS_PER_INST; ++i) {
+                const int row = i * ROWS_PER_INST + rr;
+                v[i] = *reinterpret_cast<FA_LDS const u32x4*>(region + row * ROWB + (((cc ^ row) & (CHUNKS - 1)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 32 * R / ROWS_PER_INST; ++i)
+                *reinterpret_cast<u32x4*>(Oh + (int64_t)(row0 + i * ROWS_PER_INST + rr) * oS_bytes + cc * 16) = v[i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 32 * R / ROWS_PER_INST; ++i) {
             const int row = i * ROWS_PER_INST + rr;
@@ -494,6 +506,14 @@ struct WaveCompute {
                         *reinterpret_cast<FA_LDS f32x4*>(region + (32 * r + q) * 256 + (((cidx ^ q) & 15) << 4)) = v;
                     }
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): only this wave's own ds_writes have to land
+            if (!C::PAD && row0 + 32 * R <= S) {   // (wave-uniform) every row of the wave exists
+                f32x4 v[8 * R];
+#pragma unroll
+                for (int i = 0; i < 8 * R; ++i) v[i] = *reinterpret_cast<FA_LDS const f32x4*>(region + (4 * i + rr) * 256 + (((cc ^ (4 * i + rr)) & 15) << 4));
+#pragma unroll
+                for (int i = 0; i < 8 * R; ++i) *reinterpret_cast<f32x4*>(Oh + (int64_t)(row0 + 4 * i + rr) * oS_bytes + hf * 256 + cc * 16) = v[i];
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 8 * R; ++i) {
                 const int row = 4 * i + rr;

@@ -415,6 +415,18 @@ struct WaveCompute16 {
                 *reinterpret_cast<FA_LDS u32x2*>(region + q * ROWB + (((chunk ^ q) & (CHUNKS - 1)) << 4) + half8) = v;
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): only this wave's own ds_writes have to land
+            if (!C::PAD && row0 + 32 <= S) {   // (wave-uniform) every row of the wave exists
+                u32x4 v[16 / ROWS_PER_INST];
+#pragma unroll
+                for (int i = 0; i < 16 / ROWS_PER_INST; ++i) {
+                    const int row = i * ROWS_PER_INST + rr;
+                    v[i] = *reinterpret_cast<FA_LDS const u32x4*>(region + row * ROWB + (((cc ^ row) & (CHUNKS - 1)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 16 / ROWS_PER_INST; ++i)
+                    *reinterpret_cast<u32x4*>(Oh + (int64_t)(row0 + 16 * qg + i * ROWS_PER_INST + rr) * oS_bytes + cc * 16) = v[i];
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 16 / ROWS_PER_INST; ++i) {
                 const int row = i * ROWS_PER_INST + rr, grow = row0 + 16 * qg + row;
@@ -446,6 +458,14 @@ struct WaveCompute16 {
                     *reinterpret_cast<FA_LDS f32x4*>(region + q * 256 + (((cidx ^ q) & 15) << 4)) = v;
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
+                if (!C::PAD && row0 + 32 <= S) {   // (wave-uniform) every row of the wave exists
+                    f32x4 v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<FA_LDS const f32x4*>(region + (4 * i + rr) * 256 + (((cc ^ (4 * i + rr)) & 15) << 4));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Oh + (int64_t)(row0 + 16 * qg + 4 * i + rr) * oS_bytes + hf * 256 + cc * 16) = v[i];
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = 4 * i + rr, grow = row0 + 16 * qg + row;

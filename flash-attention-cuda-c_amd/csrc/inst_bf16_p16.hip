@@ -33,4 +33,18 @@ hipError_t launch_bf16_p16(const Params& p, const fa_launch_plan& plan, bool cau
     return causal ? by_out<64, true>(p, plan, o_dtype, st) : by_out<64, false>(p, plan, o_dtype, st);
 }
 
+namespace {
+template <int D, bool CAUSAL>
+int lds_by_out(int o_dtype) {
+    if (o_dtype == FA_DTYPE_F32) return P16Cfg<D, CAUSAL, float>::LDS_BYTES;
+    if (o_dtype == FA_DTYPE_BF16) return P16Cfg<D, CAUSAL, __bf16>::LDS_BYTES;
+    return P16Cfg<D, CAUSAL, _Float16>::LDS_BYTES;
+}
+}  // namespace
+
+int bf16_p16_lds_bytes(bool causal, int d, int o_dtype) {
+    if (d == 128) return causal ? lds_by_out<128, true>(o_dtype) : lds_by_out<128, false>(o_dtype);
+    return causal ? lds_by_out<64, true>(o_dtype) : lds_by_out<64, false>(o_dtype);
+}
+
 }  // namespace fa

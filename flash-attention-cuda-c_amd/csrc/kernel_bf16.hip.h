@@ -98,7 +98,7 @@ using WaveComputeOf = std::conditional_t<C::M16, WaveCompute16<C>, WaveCompute<C
 template <class C, bool TRACK>
 __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>& w, typename WaveComputeOf<C>::Stage& st, lds_ptr smem,
                                                int n_tiles, int my_tiles, int q_row0, int lane,
-                                               unsigned long long (&acc)[15], bool tile0_in_flight) {
+                                               unsigned long long (&acc)[24], bool tile0_in_flight) {
     using G = TileGeom<C::D, C::ESZ>;
     constexpr bool CAUSAL = C::CAUSAL;
     constexpr int KVBLK = 64, SLOT = G::SLOT, KT = G::K_TILE;
@@ -118,7 +118,10 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
     // tile 1 is fetched while S(0) = K(0).Q^T and its row max are computed.
     if (!tile0_in_flight) st.load_all_into(0, smem);
     st.write_all(smem);
+    unsigned long long tw0 = 0;
+    if constexpr (C::STAMP) tw0 = cycle_stamp();
     st.wait_all();
+    if constexpr (C::STAMP) acc[16] += cycle_stamp() - tw0;   // (vmcnt(0): tile 0's pieces AND the previous unit's output stores)
     __syncthreads();
     st.load_all_into(1, smem + SLOT);          // past-the-end tiles read as zeros (buffer range check)
     constexpr int AHEAD = C::RING - 1;                 // iteration t stages tile t + AHEAD
@@ -193,6 +196,7 @@ __device__ __forceinline__ bool work_unit(const Params& p, int round, int& g, in
     g = u / p.nQ;
     qb = u - g * p.nQ;
     if (C::CAUSAL) qb = p.nQ - 1 - qb;  // heaviest query blocks of a head first
+    qb += p.qb0;
     return true;
 }
 
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(64 * C::NWAVES, 2) void fwd_mfma_kernel(const Param
     st.load_all_into(0, smem);                      // tile 0 and Q travel together (one HBM round trip)
     if constexpr (C::COALESCED_Q) w.load_q_rows(cur.Qh, qSb, cur.q_row0, S, lane);
     else w.load_q(cur.Qh, qSb, cur.q_row0, S, lane, row_bytes);
-    unsigned long long acc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if constexpr (C::STAMP) acc[12] = cycle_stamp() - t_kernel0;   // setup: unit decode, descriptors, first loads issued
 
     while (true) {
@@ -313,8 +317,14 @@ __global__ __launch_bounds__(64 * C::NWAVES, 2) void fwd_mfma_kernel(const Param
         }
         if constexpr (C::STAMP) acc[4] += cycle_stamp() - t_ep0;   // epilogue: normalise + store O (issue side)
         if (!more) break;
-        // the next prologue overwrites ring slots that other waves' epilogue regions alias
-        __syncthreads();
+        // register-staged kernels: the next prologue's ds_writes of tile 0 alias other waves' epilogue regions
+        unsigned long long t_b0 = 0;
+        if constexpr (C::STAMP) t_b0 = cycle_stamp();
+        // (LDS-DMA kernels need no barrier here: a wave's Q staging region IS its epilogue region, tile 0 lands in slot 0 in front of
+        //  them, and slot 1 is first written behind the next pass's first barrier -- nothing the next prologue writes before that
+        //  barrier aliases another wave's epilogue region.  +1.4 % non-causal with fp32 output, profiles/r03_tune_a_*.log)
+        if constexpr (!C::DMA) __syncthreads();
+        if constexpr (C::STAMP) acc[15] += cycle_stamp() - t_b0;   // waiting for the slowest wave's epilogue
         cur = nxt;
     }
     if constexpr (C::STAMP) {
@@ -324,11 +334,9 @@ __global__ __launch_bounds__(64 * C::NWAVES, 2) void fwd_mfma_kernel(const Param
         acc[14] = t_end - t_tail0;
         acc[0] = t_end - t_kernel0;                        // whole workgroup lifetime of this wave
         if (lane == 0 && p.dbg) {
+            acc[11] = 1;   // (rows of waves that do not exist stay 0)
 #pragma unroll
-            for (int k = 0; k < 11; ++k) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + k] = acc[k];
-            p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 11] = 1;   // (rows of waves that do not exist stay 0)
-#pragma unroll
-            for (int k = 12; k < 15; ++k) p.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + k] = acc[k];
+            for (int k = 0; k < 24; ++k) p.dbg[((size_t)blockIdx.x * 8 + wave) * 24 + k] = acc[k];
         }
     }
 }

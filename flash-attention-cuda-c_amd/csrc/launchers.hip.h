@@ -44,5 +44,6 @@ int f32_lds_bytes(int d_padded);
 int bf16_d128_lds_bytes(bool causal, bool pad, int o_dtype);
 int bf16_d64_lds_bytes(bool causal, bool pad, int o_dtype);
 int fp8_d128_lds_bytes(bool causal, bool pad, int o_dtype);
+int bf16_p16_lds_bytes(bool causal, int d, int o_dtype);
 
 }  // namespace fa

@@ -41,7 +41,8 @@ struct Params {
     int B, H, S;      // S = query rows per head
     int Sk;           // keys (rows of K and V) per head; == S for self-attention
     int d;            // head dimension of the tensors (<= the kernel's compile-time D: narrower rows are zero-padded)
-    int nQ;           // query blocks per head
+    int nQ;           // query blocks per head handled by THIS launch: blocks qb0 .. qb0 + nQ - 1 (a call may be split into two launches)
+    int qb0;          // first of them
     int units;        // B*H*nQ
     int cpx;          // ceil(units / 8): work units per XCD group
     int jpx;          // persistent grid only: workgroups per XCD group (grid / 8)

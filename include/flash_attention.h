@@ -62,17 +62,32 @@ enum {
     FA_ERR_UNSUPPORTED_DTYPE = -5,
     FA_ERR_BAD_SCALE = -6,        /* scale is NaN or infinite (fp8 inputs: or not positive) */
     FA_ERR_BAD_STRIDE = -7,
-    FA_ERR_BAD_FLAGS = -8         /* flash_attention_ex: unknown flag, or one that does not apply to this dtype / dHead */
+    FA_ERR_BAD_FLAGS = -8         /* flash_attention_ex: unknown flag, contradictory flags, or one that does not apply to this dtype / dHead */
 };
 
-/* Option flags of flash_attention_ex. */
+/*
+ * Precision of the softmax weights on the bf16 path (bf16 inputs, dHead 64 or 128).
+ *
+ * The weights P = exp(scale*S - max) are rounded before the P.V product: to bf16 (8 significant bits), or to fp16 (11 bits)
+ * with V converted bf16 -> fp16 on its way into LDS (exact for |v| in [2^-14, 65504]; LARGER |v| BECOMES inf).  The rounding
+ * errors of a row's weights average out over its keys, so a row that sees thousands of keys meets the tolerance stated against
+ * check.py, |O-ref| <= 1e-3 + 1e-3|ref| (reference check.py:19-21), with bf16 weights, while a row that sees a few dozen does
+ * not (the first rows of a causal problem: measured 1.3 x the tolerance at 64 visible keys, 0.9 x at 256, 0.74 x at 1024).
+ *
+ *   default (flags = 0)    rows that can see fewer than FA_EARLY_KEYS keys take fp16 weights, all others bf16 weights: under the
+ *                          causal mask the query rows q < FA_EARLY_KEYS of every head (whole 256-row query blocks; a second,
+ *                          small launch on the same stream), and every row when seqLenK < FA_EARLY_KEYS.  Meets the stated
+ *                          tolerance on every element with fp32 output; costs ~1 % at seqLen 4096.
+ *   FA_FLAG_F16_WEIGHTS    fp16 weights on every row (-7 % throughput; 8-13 x smaller errors).
+ *   FA_FLAG_BF16_WEIGHTS   bf16 weights on every row: the fastest form, for callers whose |V| may exceed 65504 or who accept
+ *                          ~0.006 % of a causal problem's elements (its first rows) outside the stated tolerance.
+ * Other dHead (zero-padded instantiations), fp8 and fp32 inputs have one form each and ignore none of this: the two flags are
+ * rejected (FA_ERR_BAD_FLAGS) where they cannot apply, except FA_FLAG_BF16_WEIGHTS on any bf16 problem.
+ */
+#define FA_EARLY_KEYS 1024
 enum {
-    /* bf16 inputs, dHead 64 or 128: round the softmax weights to fp16 (11 significant bits) instead of bf16 (8) before P.V,
-     * with V converted bf16 -> fp16 (exact for |v| in [2^-14, 65504]) on its way into LDS.  Same MFMA rate; one conversion pass
-     * over V per tile more.  This is the variant that meets the stated |O-ref| <= 1e-3 + 1e-3|ref| against check.py
-     * (reference check.py:19-21) on > 99.9 % of the elements where the bf16-weights default leaves ~0.5 % of a causal
-     * problem's early rows outside it.  |V| > 65504 becomes inf. */
-    FA_FLAG_F16_WEIGHTS = 1
+    FA_FLAG_F16_WEIGHTS = 1,
+    FA_FLAG_BF16_WEIGHTS = 2
 };
 
 /*
@@ -127,6 +142,11 @@ int flash_attention_strided(const void* Q, const void* K, const void* V, void* O
  * statistic of the reference's commented-out first API (kernels/FlashAttention.cuh:21,
  * archive/archive.cu:34-42,201-204) and what a backward pass, split-KV or ring composition needs.
  * LSE may be NULL (then identical to flash_attention()).
+ * O with and without an LSE request: the kernels that return the LSE normalise by the fp32 sum of the UNROUNDED softmax weights
+ * (so that the LSE is exact to fp32 rounding); bf16 inputs without the causal mask and without an LSE request normalise by the
+ * sum of the ROUNDED weights instead (it comes out of the matrix cores with the P.V product).  The two differ by the weights'
+ * rounding averaged over a row: at most one ulp of a bf16 output, <= 2^-9 relative in fp32.  A caller that compares a sharded
+ * run with a whole one bit for bit asks for the LSE on both sides or on neither.
  */
 int flash_attention_lse(const void* Q, const void* K, const void* V, void* O, float* LSE,
                         int batchSize, int numHeads, int seqLen, int dHead,
@@ -151,6 +171,7 @@ int flash_attention_cross(const void* Q, const void* K, const void* V, void* O, 
 
 /*
  * flash_attention_ex -- flash_attention_cross() plus option flags (FA_FLAG_*); flags = 0 is flash_attention_cross().
+ * flash_attention(), _lse(), _strided(), _cross() and _sharded() all run with flags = 0.
  */
 int flash_attention_ex(const void* Q, const void* K, const void* V, void* O, float* LSE,
                        int batchSize, int numHeads, int seqLenQ, int seqLenK, int dHead,
@@ -207,6 +228,23 @@ typedef struct fa_launch_plan {
 
 int flash_attention_plan(int batchSize, int numHeads, int seqLen, int dHead, bool is_causal,
                          int dtype, int o_dtype, fa_launch_plan* plan);
+
+/*
+ * flash_attention_plan_ex -- the launches a flash_attention_ex() call with these arguments makes.  A bf16 problem may be split
+ * in two (see "Precision of the softmax weights"): `early` describes the fp16-weights launch over the first
+ * early->q_blocks query blocks of every head, `main` the launch over the remaining main->q_blocks; a launch that does not
+ * happen has q_blocks = 0 and grid = 0.  lds_bytes is the launched instantiation's own figure (it depends on the engine, the
+ * staging form and the output type).  flash_attention_plan() is this call with seqLenK = seqLen, flags = FA_FLAG_BF16_WEIGHTS
+ * (one launch) and only `main` returned.  Either pointer may be NULL.
+ */
+typedef struct fa_launch_plan_ex {
+    fa_launch_plan launch;
+    int q_blocks;        /* query blocks of every head this launch covers */
+    int first_q_block;   /* ... starting at this one */
+} fa_launch_plan_ex;
+
+int flash_attention_plan_ex(int batchSize, int numHeads, int seqLenQ, int seqLenK, int dHead, bool is_causal,
+                            int dtype, int o_dtype, unsigned flags, fa_launch_plan_ex* early, fa_launch_plan_ex* main);
 
 /* Human-readable text for a return code of the functions above (static storage). */
 const char* flash_attention_error_string(int code);

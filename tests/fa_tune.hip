@@ -74,13 +74,14 @@ template <int D, bool CAUSAL>
 static std::vector<Variant> make_variants() {
     using T = __bf16;
     std::vector<Variant> v;
-    v.push_back({"production (16x16x32 non-causal, 32x32x16 causal)", launch_cfg<ProdCfg<D, CAUSAL, T>>});
+    constexpr int M = CAUSAL ? 0 : -1;   // production engine choice
+    v.push_back({"production (16x16x32 non-causal, 32x32x16 causal), bf16 O", launch_cfg<ProdCfg<D, CAUSAL, T>>});
+    v.push_back({"fp32 O (production)", launch_cfg<ProdCfg<D, CAUSAL, float>>, 4});
+    v.push_back({"production STAMP, bf16 O", launch_cfg<ProdCfg<D, CAUSAL, T, 2, true>>});
+    v.push_back({"production STAMP, fp32 O", launch_cfg<ProdCfg<D, CAUSAL, float, 2, true>>, 4});
     v.push_back({"the other engine", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = CAUSAL ? 1 : 0}>>});
     v.push_back({"fp16 weights (FA_FLAG_F16_WEIGHTS)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>});
     v.push_back({"exact row sums (the LSE instantiation)", launch_cfg<ProdCfg<D, CAUSAL, T, 2, false, false, true>>});
-    v.push_back({"fp32 O (production)", launch_cfg<ProdCfg<D, CAUSAL, float>>, 4});
-    v.push_back({"production STAMP", launch_cfg<ProdCfg<D, CAUSAL, T, 2, true>>});
-    v.push_back({"fp32 O STAMP", launch_cfg<ProdCfg<D, CAUSAL, float, 2, true>>, 4});
     return v;
 }
 
@@ -153,8 +154,8 @@ int main(int argc, char** argv) {
     p.scale_log2 = p.scale * 1.4426950408889634f;
     const int grid = 8 * p.cpx;
     unsigned long long* ddbg;
-    HIP_CHECK(hipMalloc(&ddbg, (size_t)grid * 128 * 8));
-    HIP_CHECK(hipMemset(ddbg, 0, (size_t)grid * 128 * 8));
+    HIP_CHECK(hipMalloc(&ddbg, (size_t)grid * 192 * 8));
+    HIP_CHECK(hipMemset(ddbg, 0, (size_t)grid * 192 * 8));
     p.dbg = ddbg;
 
     std::vector<Variant> vars;
@@ -219,7 +220,7 @@ int main(int argc, char** argv) {
     std::vector<std::vector<float>> ms(vars.size());
     for (size_t vi = 0; vi < vars.size(); ++vi) { vars[vi].launch(p, grid); vars[vi].launch(p, grid); }
     HIP_CHECK(hipDeviceSynchronize());
-    HIP_CHECK(hipMemset(ddbg, 0, (size_t)grid * 128 * 8));   // stamp rows: only the STAMP variant(s) timed below write them
+    HIP_CHECK(hipMemset(ddbg, 0, (size_t)grid * 192 * 8));   // stamp rows: only the STAMP variant(s) timed below write them
     // every round visits the variants in a fresh (seeded) random order: a variant's clock depends on what ran just before it
     // (a fixed order gave identical kernels 3.6 % apart), so the predecessor must not be the same in every round
     std::vector<size_t> order(vars.size());
@@ -242,29 +243,31 @@ int main(int argc, char** argv) {
         }
     }
     {   // segment stamps of the STAMP variant (if it ran)
-        std::vector<unsigned long long> h((size_t)grid * 128);
+        std::vector<unsigned long long> h((size_t)grid * 192);
         HIP_CHECK(hipMemcpy(h.data(), ddbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double seg[15] = {0};
+        double seg[24] = {0};
         for (size_t i = 0; i < (size_t)grid * 8; ++i)
-            for (int k = 0; k < 15; ++k) seg[k] += (double)h[i * 16 + k];
+            for (int k = 0; k < 24; ++k) seg[k] += (double)h[i * 24 + k];
         if (seg[6] > 0) {
             const double nt = seg[6], nw = seg[11] > 0 ? seg[11] : 1;
             printf("  STAMP build (each stamp costs ~40-60 cycles):\n");
             printf("    per tile per wave (%.0f wave-tiles): phase A %.1f | phase B %.1f | end-of-tile %.1f | barrier %.1f | sum %.1f\n", nt,
                    seg[1] / nt, seg[2] / nt, seg[3] / nt, seg[5] / nt, (seg[1] + seg[2] + seg[3] + seg[5]) / nt);
             for (int wv = 0; wv < 8; ++wv) {   // per wave index: does the older half (waves 0-3) wait at the barrier?
-                double a = 0, b = 0, bar = 0, n = 0;
+                double a = 0, b = 0, bar = 0, n = 0, ep = 0, epb = 0, w0 = 0, nwv = 0;
                 for (size_t g = 0; g < (size_t)grid; ++g) {
-                    const unsigned long long* r = &h[(g * 8 + wv) * 16];
+                    const unsigned long long* r = &h[(g * 8 + wv) * 24];
                     a += (double)r[1]; b += (double)r[2]; bar += (double)r[5]; n += (double)r[6];
+                    ep += (double)r[4]; epb += (double)r[15]; w0 += (double)r[16]; nwv += (double)r[11];
                 }
-                if (n > 0) printf("      wave %d: phase A %.0f  phase B %.0f  barrier wait %.0f\n", wv, a / n, b / n, bar / n);
+                if (n > 0) printf("      wave %d: phase A %.0f  phase B %.0f  barrier wait %.0f   | per workgroup-wave: epilogue issue %.0f  post-epilogue barrier %.0f  prologue vmcnt(0) %.0f\n",
+                                  wv, a / n, b / n, bar / n, ep / nwv, epb / nwv, w0 / nwv);
             }
             {   // spread of workgroup lifetimes (wave 0 of each): a static schedule ends with its slowest workgroup
                 double mn = 1e30, mx = 0, sum = 0; int cnt = 0;
                 double xsum[8] = {0}; int xcnt[8] = {0};
                 for (size_t g = 0; g < (size_t)grid; ++g) {
-                    const double life = (double)h[(g * 8) * 16 + 0];
+                    const double life = (double)h[(g * 8) * 24 + 0];
                     if (life <= 0) continue;
                     mn = std::min(mn, life); mx = std::max(mx, life); sum += life; ++cnt;
                     xsum[g & 7] += life; ++xcnt[g & 7];
@@ -279,8 +282,9 @@ int main(int argc, char** argv) {
             printf("    per workgroup-wave (%.0f waves): lifetime %.0f = Q load+pin %.0f | stage tiles 0,1 + barrier %.0f | QK(0)+max %.0f | tile loop %.0f (%.1f%%) | finite check %.0f | epilogue %.0f | unaccounted %.0f\n",
                    nw, tot, seg[7] / nw, seg[8] / nw, seg[9] / nw, loop, 100 * loop / tot, seg[10] / nw, seg[4] / nw,
                    tot - loop - (seg[7] + seg[8] + seg[9] + seg[10] + seg[4]) / nw);
-            printf("      of the unaccounted: setup (unit decode, descriptors, first loads issued) %.0f | next unit decode + prefetch issue %.0f | store tail (vmcnt(0) at exit) %.0f\n",
-                   seg[12] / nw, seg[13] / nw, seg[14] / nw);
+            printf("      of the unaccounted: setup (unit decode, descriptors, first loads issued) %.0f | next unit decode + prefetch issue %.0f | store tail (vmcnt(0) at exit) %.0f | post-epilogue barrier %.0f\n",
+                   seg[12] / nw, seg[13] / nw, seg[14] / nw, seg[15] / nw);
+            printf("      inside 'stage tiles 0,1 + barrier': the first vmcnt(0) of the prologue %.0f\n", seg[16] / nw);
         }
     }
     const double flops = (causal ? 2.0 : 4.0) * BH * (double)S * S * d;

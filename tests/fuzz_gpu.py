@@ -4,6 +4,10 @@ As a module (tests/test_fuzz_slice.py): `draw_cases(seed, n)` replays the seeded
 the GPU and returns the observed errors next to every term of the bound they are held to.
 As a script (long sweeps, by hand on a GPU box):  python tests/fuzz_gpu.py --cases 600 --seed 7 > gpurun_out/fuzz.log
 
+Every case also flips two coins (from a side generator, so the logged case numbers of earlier rounds still replay): whether the call
+asks for the LSE -- without it, non-causal bf16 inputs run the instantiation bench.py times (row sums by MFMA) -- and the softmax-weight
+precision (library default / bf16 everywhere / fp16 everywhere).
+
 Each case draws dtype (bf16 / fp8 e4m3fn / fp32), B, H, Sq, Sk (60 % square), d, causal, layout (dense or (B,S,H*d)
 model-layout views), output dtype and a score scale that sometimes forces the optimistic pass to fall back, and checks O and
 LSE element-wise against a bound derived from the arithmetic the kernel is documented to do (DESIGN.md "Tolerance").
@@ -65,13 +69,23 @@ def draw_cases(seed, n):
         if B * H * max(Sq, Sk) * d > 6_000_000:
             H = max(1, H // 4)
         data_seed = int(rng.integers(0, 2**31))
+        # Later additions draw from a generator of their own, keyed on (seed, i): the main stream above -- and with it every
+        # logged (seed, case number) -- stays what it was.
+        #   lse      the call also asks for the LSE or not: for bf16 inputs without the mask these are DIFFERENT instantiations (row
+        #            sums by MFMA over the rounded weights / by v_add_f32 over the unrounded ones); the no-LSE one is what bench.py times
+        #   weights  None = library default (fp16 weights on rows that see < 1024 keys), or one precision on every row
+        rng2 = np.random.default_rng([seed, i, 20261004])
+        lse = bool(rng2.integers(0, 2))
+        weights = [None, None, torch.bfloat16, torch.float16][int(rng2.integers(0, 4))]
+        if dtype != torch.bfloat16 or (weights == torch.float16 and d not in (64, 128)):
+            weights = None
         yield dict(i=i, seed=seed, dtype=dtype, B=B, H=H, Sq=Sq, Sk=Sk, d=d, causal=causal, strided=strided,
-                   out_dtype=out_dtype, boost=boost, data_seed=data_seed)
+                   out_dtype=out_dtype, boost=boost, data_seed=data_seed, lse=lse, weights=weights)
 
 
 def describe(c):
     return (f"seed {c['seed']} case {c['i']}: dtype={c['dtype']} B={c['B']} H={c['H']} Sq={c['Sq']} Sk={c['Sk']} d={c['d']} "
-            f"causal={c['causal']} strided={c['strided']} out={c['out_dtype']} boost={c['boost']}")
+            f"causal={c['causal']} strided={c['strided']} out={c['out_dtype']} boost={c['boost']} lse={c.get('lse', True)} weights={c.get('weights')}")
 
 
 def run_case(c):
@@ -84,7 +98,9 @@ def run_case(c):
     Qd, Kd, Vd = view(Qm.to(DEV), Sq), view(Km.to(DEV), Sk), view(Vm.to(DEV), Sk)
     if not c["strided"]:
         Qd, Kd, Vd = Qd.contiguous(), Kd.contiguous(), Vd.contiguous()
-    O, lse = fa.flash_attention(Qd, Kd, Vd, is_causal=c["causal"], out_dtype=c["out_dtype"], return_lse=True)
+    want_lse = c.get("lse", True)
+    res = fa.flash_attention(Qd, Kd, Vd, is_causal=c["causal"], out_dtype=c["out_dtype"], return_lse=want_lse, weights_dtype=c.get("weights"))
+    O, lse = res if want_lse else (res, None)
     torch.cuda.synchronize()
     f = lambda t, S: view(t, S).float().numpy()
     qn, kn, vn = f(Qm, Sq), f(Km, Sk), f(Vm, Sk)
@@ -94,7 +110,7 @@ def run_case(c):
     scale = 1.0 / np.sqrt(d)
     s = (qn.astype(np.float64) @ np.swapaxes(kn.astype(np.float64), -1, -2)) * scale
     smax = float(np.abs(s).max())
-    Oh, lh = O.float().cpu().numpy(), lse.cpu().numpy()
+    Oh, lh = O.float().cpu().numpy(), (lse.cpu().numpy() if want_lse else lref.astype(np.float32))   # (no LSE asked for: nothing to compare)
     fp8 = dtype == FP8
     # ---- O ----
     if dtype == torch.float32:

@@ -48,8 +48,8 @@ def test_argument_validation_happens_before_any_launch():
     assert call(dtype=2, d=64, scale=-1.0) == -6                     # fp8: MFMA path only, which needs scale > 0 -> FA_ERR_BAD_SCALE
     assert call(dtype=9) == -5 and call(o=2) == -5                   # FA_ERR_UNSUPPORTED_DTYPE
     assert call(scale=float("nan")) == -6 and call(scale=float("inf")) == -6
-    for code in range(-7, 1):
-        assert fa.error_string(code)
+    for code in range(-8, 1):
+        assert fa.error_string(code) and "unknown flash_attention error" not in fa.error_string(code)
     assert "null" in fa.error_string(-1)
 
 
@@ -124,3 +124,28 @@ def test_shard_range_matches_the_python_partition():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(fa.FlashAttentionError):
         fa.shard_range(8, 3, 2)
+
+
+def test_plan_ex_describes_both_launches():
+    """flash_attention_plan_ex: the launches a call makes.  bf16, d = 128, causal, S = 4096: the first FA_EARLY_KEYS / 256 = 4 query
+    blocks of every head go to the fp16-weights kernel, the other 12 to the bf16-weights kernel; the flags move the split."""
+    early, main = fa.plan_ex(8, 16, 4096, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, 0)
+    assert (early["first_q_block"], early["q_blocks"], main["first_q_block"], main["q_blocks"]) == (0, 4, 4, 12)
+    assert early["grid"] == 256 and main["grid"] == 256 and early["threads"] == main["threads"] == 512
+    assert early["lds_bytes"] > 0 and main["lds_bytes"] == fa.plan(8, 16, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["lds_bytes"]
+    early, main = fa.plan_ex(8, 16, 4096, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, fa.FA_FLAG_BF16_WEIGHTS)
+    assert (early["q_blocks"], early["grid"], main["q_blocks"]) == (0, 0, 16)
+    early, main = fa.plan_ex(8, 16, 4096, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, fa.FA_FLAG_F16_WEIGHTS)
+    assert (early["q_blocks"], main["q_blocks"], main["grid"]) == (16, 0, 0)
+    # without the mask only short key sequences are "early"
+    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 4096, 4096, 128, False)] == [0, 16]
+    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 4096, 1000, 128, False)] == [16, 0]
+    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 64, True)] == [3, 0]
+    # padded head dimensions, fp32 and fp8 inputs have one form
+    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 80, True)] == [0, 3]
+    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 128, True, fa.FA_DTYPE_F32)][0] == 0
+    L = fa.lib()
+    assert L.flash_attention_plan_ex(1, 1, 64, 64, 128, False, fa.FA_DTYPE_BF16, 0, 3, None, None) == -8      # contradictory flags
+    assert L.flash_attention_plan_ex(1, 1, 64, 64, 80, False, fa.FA_DTYPE_BF16, 0, 1, None, None) == -8       # no fp16-weights kernel at d = 80
+    assert L.flash_attention_plan_ex(1, 1, 64, 64, 128, False, fa.FA_DTYPE_F32, 0, 2, None, None) == -8       # flag on fp32 inputs
+    assert L.flash_attention_plan_ex(1, 1, 64, 64, 128, False, fa.FA_DTYPE_BF16, 0, 8, None, None) == -8      # unknown flag
