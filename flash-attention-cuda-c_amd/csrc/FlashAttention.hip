@@ -218,14 +218,22 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
         e = launch_fp8_d128(p, plan, causal, d != 128, o_dtype, st);
     } else if (plan.kernel_id == 1) {   // bf16 inputs
         // Which query blocks take fp16 softmax weights (early_q_blocks): all with FA_FLAG_F16_WEIGHTS, none with
-        // FA_FLAG_BF16_WEIGHTS, by default the rows that see few keys.  Two launches on the same stream, disjoint output rows.
+        // FA_FLAG_BF16_WEIGHTS, by default the rows that see few keys.  Both kinds present (a causal problem longer than
+        // FA_EARLY_KEYS): ONE launch whose workgroups walk the late blocks with the bf16-weights kernel, then the early blocks with
+        // the fp16-weights kernel (disjoint output rows).
         const int hp = early_q_blocks(S, Sk, d, causal, flags, plan.q_block_rows);
-        if (hp > 0) {
+        if (hp > 0 && hp < nQ_total && causal) {   // (without the mask early_q_blocks is all or nothing)
+            set_range(hp, nQ_total - hp, true);
+            const Params late = p;
+            const int grid_late = plan.grid;
+            set_range(0, hp, true);
+            plan.grid = std::max(plan.grid, grid_late);
+            e = launch_bf16_causal_dual(late, p, plan, d, o_dtype, st);
+        } else if (hp > 0) {
             set_range(0, hp, true);
             e = launch_bf16_p16(p, plan, causal, d, o_dtype, st);
-        }
-        if (e == hipSuccess && hp < nQ_total) {
-            set_range(hp, nQ_total - hp, true);
+        } else {
+            set_range(0, nQ_total, true);
             e = d > 64 ? launch_bf16_d128(p, plan, causal, d != 128, o_dtype, st) : launch_bf16_d64(p, plan, causal, d != 64, o_dtype, st);
         }
     } else {
@@ -380,6 +388,13 @@ int flash_attention_plan_ex(int batchSize, int numHeads, int seqLenQ, int seqLen
     };
     fill(early, 0, hp, true);
     fill(main_, hp, nQ - hp, false);
+    if (hp > 0 && hp < nQ) {   // both ranges: one launch (fwd_mfma_dual_kernel) over the larger grid with the larger LDS carve-up
+        const int64_t ue = (int64_t)batchSize * numHeads * hp, um = (int64_t)batchSize * numHeads * (nQ - hp);
+        const int grid = (int)(8 * std::min<int64_t>((std::max(ue, um) + 7) / 8, fa::device_cus() / 8));
+        const int lds = fa::bf16_causal_dual_lds_bytes(dHead, o_dtype);
+        if (early) { early->launch.grid = grid; early->launch.lds_bytes = lds; }
+        if (main_) { main_->launch.grid = grid; main_->launch.lds_bytes = lds; }
+    }
     return FA_OK;
 }
 

@@ -83,6 +83,17 @@ struct WaveCompute16 {
     unsigned long long t_mid = 0, t_end = 0;   // STAMP builds only
 
     __host__ __device__ static constexpr int elem_slot(int E) { return E * SPAN / NE; }
+    // overall slot (0 .. SA + SB - 1) that issues staging load / LDS-DMA piece n of the tile two ahead: the odd slots from 1 on.
+    // (Later is worse -- the pieces then land after the end-of-step wait: phase A's second half -2.6 %, phase B -9 ... -13 %,
+    //  profiles/r03_tune_c_dma_slots_*.log.)
+    __host__ __device__ static constexpr int load_slot(int n) { return 1 + 2 * n; }
+    template <int SLOT, int N = 0>
+    __device__ __forceinline__ void load_in_slot(Stage& st, int t_load) {
+        if constexpr (N < NL) {
+            if constexpr (load_slot(N) == SLOT) st.template load<N>(t_load);
+            load_in_slot<SLOT, N + 1>(st, t_load);
+        }
+    }
 
     __device__ __forceinline__ void init() {
 #pragma unroll
@@ -290,7 +301,7 @@ struct WaveCompute16 {
                 constexpr int v = I - (SA - VPRE);
                 vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DG, v % DG);
             }
-            if constexpr ((I & 1) && (I >> 1) < NL) st.template load<(I >> 1)>(t_load);
+            load_in_slot<I>(st, t_load);
             if constexpr (!C::VALU_FIRST) exp_slot<I>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
             slots_a<I + 1>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
@@ -424,7 +435,7 @@ struct WaveCompute16 {
                 }
 #pragma unroll
                 for (int i = 0; i < 16 / ROWS_PER_INST; ++i)
-                    *reinterpret_cast<u32x4*>(Oh + (int64_t)(row0 + 16 * qg + i * ROWS_PER_INST + rr) * oS_bytes + cc * 16) = v[i];
+                    store_global_b128<C::O_CACHE>(Oh + (int64_t)(row0 + 16 * qg + i * ROWS_PER_INST + rr) * oS_bytes + cc * 16, v[i]);
                 continue;
             }
 #pragma unroll
@@ -463,7 +474,7 @@ struct WaveCompute16 {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<FA_LDS const f32x4*>(region + (4 * i + rr) * 256 + (((cc ^ (4 * i + rr)) & 15) << 4));
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Oh + (int64_t)(row0 + 16 * qg + 4 * i + rr) * oS_bytes + hf * 256 + cc * 16) = v[i];
+                    for (int i = 0; i < 4; ++i) store_global_b128<C::O_CACHE>(Oh + (int64_t)(row0 + 16 * qg + 4 * i + rr) * oS_bytes + hf * 256 + cc * 16, __builtin_bit_cast(u32x4, v[i]));
                     continue;
                 }
 #pragma unroll

@@ -6,10 +6,6 @@
 namespace fa {
 namespace {
 
-// weights rounded to fp16, V staged as fp16, fp32 sum of the unrounded weights (so the LSE is exact too)
-template <int D, bool CAUSAL, typename OutT>
-using P16Cfg = KernelCfg<D, CAUSAL, OutT, 2, Opt{.sum_mfma = 0, .p_f16 = true}>;
-
 template <class Cfg>
 hipError_t launch_mfma(const Params& p, const fa_launch_plan& plan, hipStream_t st) {
     static std::atomic<bool> done[64];

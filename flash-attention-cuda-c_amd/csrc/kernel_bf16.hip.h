@@ -51,6 +51,11 @@ struct KernelCfg {
     using OutT = OutT_;
     static constexpr int ESZ = ESZ_;                 // bytes per Q/K/V element: 2 = bf16, 1 = fp8 e4m3fn
     static constexpr bool STAMP = O.stamp, PAD = O.pad;
+    // Cache policy of the output stores (utils.hip.h: store_global_b128): non-temporal under the causal mask -- O is written once and
+    // never read, and every line it leaves in the XCD's L2 evicts K/V lines that the head's other query blocks are about to
+    // re-read (causal, fp32 O: plain 1058, sc1 1073, nt 1076, sc0 sc1 1076 TFLOP/s; bf16 O +0.5 %; without the mask -0.3 %:
+    // profiles/r03_tune_d_output_store_policy_*.log)
+    static constexpr int O_CACHE = CAUSAL_ ? 2 : 0;
     // Q rows fetched whole and turned into fragments through LDS (q_rows_to_fragments): on at d = 128 (+0.8 %), off at d = 64
     // (the 37 us cfg1 loses 1.8 % to the extra LDS trip)
     static constexpr bool COALESCED_Q = D_ == 128 && !O.pad;
@@ -88,6 +93,11 @@ struct KernelCfg {
 // decide, and the 32x32x16 engine's lower issue pressure wins (16x16x32: -6.8 ... +1.3 %, mean -2.3 %).  DESIGN.md section 4.
 template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false, bool PAD = false, bool LSE = false>
 using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, Opt{.stamp = STAMP, .pad = PAD, .m16 = CAUSAL ? 0 : -1, .sum_mfma = LSE ? 0 : -1}>;
+
+// The fp16-weights kernels (FA_FLAG_F16_WEIGHTS, and the early query blocks of the default precision): weights rounded to fp16, V
+// staged as fp16, fp32 sum of the unrounded weights (so the LSE is exact too)
+template <int D, bool CAUSAL, typename OutT>
+using P16Cfg = KernelCfg<D, CAUSAL, OutT, 2, Opt{.sum_mfma = 0, .p_f16 = true}>;
 
 // The per-wave compute engine of a configuration: 16x16x32 MFMAs (computers16.hip.h) or 32x32x16 (computers.hip.h).
 template <class C>
@@ -226,12 +236,11 @@ struct UnitCtx {
     }
 };
 
+// Everything a workgroup does for one launch range: walk its units (work_unit) of configuration C.
 template <class C>
-__global__ __launch_bounds__(64 * C::NWAVES, 2) void fwd_mfma_kernel(const Params p) {
+__device__ __forceinline__ void run_units(const Params& p, lds_ptr smem) {
     constexpr int D = C::D, ESZ = C::ESZ;
     using OutT = typename C::OutT;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    lds_ptr smem = (lds_ptr)smem_raw;
 
     int g, qb, round = 0;
     if (!work_unit<C>(p, 0, g, qb)) return;
@@ -339,6 +348,26 @@ __global__ __launch_bounds__(64 * C::NWAVES, 2) void fwd_mfma_kernel(const Param
             for (int k = 0; k < 24; ++k) p.dbg[((size_t)blockIdx.x * 8 + wave) * 24 + k] = acc[k];
         }
     }
+}
+
+template <class C>
+__global__ __launch_bounds__(64 * C::NWAVES, 2) void fwd_mfma_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    run_units<C>(p, (lds_ptr)smem_raw);
+}
+
+// Two launch ranges in ONE launch: every workgroup first walks its units of range A (configuration CA), then its units of range B
+// (CB).  This is how the library's default precision runs a causal bf16 problem: A = the bf16-weights kernel over the query blocks
+// whose rows see >= FA_EARLY_KEYS keys, B = the fp16-weights kernel over the first query blocks of every head -- as two launches
+// the small one pays a kernel boundary and both pay their own tail (0.5287 against 0.5163 ms for one kernel over all blocks,
+// profiles/r03_tune_e_split_cost_c.log); fused, a workgroup that finishes its A units early starts on its B units.
+template <class CA, class CB>
+__global__ __launch_bounds__(64 * CA::NWAVES, 2) void fwd_mfma_dual_kernel(const Params pa, const Params pb) {
+    static_assert(CA::NWAVES == CB::NWAVES, "one workgroup shape");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    run_units<CA>(pa, (lds_ptr)smem_raw);
+    __syncthreads();   // (A's last epilogue regions and B's first ring slots alias: once per launch)
+    run_units<CB>(pb, (lds_ptr)smem_raw);
 }
 
 }  // namespace fa

@@ -80,6 +80,16 @@ __device__ __forceinline__ s16x4 lds_read_tr16_b64(lds_ptr base, int byte_off) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<FA_LDS s16x4*>(base + byte_off));
 }
 
+// 16-byte global store with a cache policy (KernelCfg::O_CACHE): 0 plain; 1 sc1 (write-through: the line does not stay in
+// the XCD's L2); 2 nt; 3 sc0 sc1.  The asm forms end in s_nop 1: hipcc must not reuse the data registers before the store has read them.
+template <int POLICY>
+__device__ __forceinline__ void store_global_b128(void* p, u32x4 v) {
+    if constexpr (POLICY == 0) *reinterpret_cast<u32x4*>(p) = v;
+    else if constexpr (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else if constexpr (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 // ---- cross-half exchange: value of lane l^32 ---------------------------------------------------
 __device__ __forceinline__ float other_half(float x) {
     // v_permlane32_swap vdst, src swaps vdst[32..63] with src[0..31]; with both = x the pair

@@ -75,9 +75,10 @@ enum {
  * not (the first rows of a causal problem: measured 1.3 x the tolerance at 64 visible keys, 0.9 x at 256, 0.74 x at 1024).
  *
  *   default (flags = 0)    rows that can see fewer than FA_EARLY_KEYS keys take fp16 weights, all others bf16 weights: under the
- *                          causal mask the query rows q < FA_EARLY_KEYS of every head (whole 256-row query blocks; a second,
- *                          small launch on the same stream), and every row when seqLenK < FA_EARLY_KEYS.  Meets the stated
- *                          tolerance on every element with fp32 output; costs ~1 % at seqLen 4096.
+ *                          causal mask the query rows q < FA_EARLY_KEYS of every head (whole 256-row query blocks; the same
+ *                          launch runs both kernels, each workgroup first its late then its early blocks), and every row when
+ *                          seqLenK < FA_EARLY_KEYS.  Meets the stated tolerance on every element with fp32 output; costs
+ *                          ~1 % at seqLen 4096.
  *   FA_FLAG_F16_WEIGHTS    fp16 weights on every row (-7 % throughput; 8-13 x smaller errors).
  *   FA_FLAG_BF16_WEIGHTS   bf16 weights on every row: the fastest form, for callers whose |V| may exceed 65504 or who accept
  *                          ~0.006 % of a causal problem's elements (its first rows) outside the stated tolerance.
@@ -230,12 +231,13 @@ int flash_attention_plan(int batchSize, int numHeads, int seqLen, int dHead, boo
                          int dtype, int o_dtype, fa_launch_plan* plan);
 
 /*
- * flash_attention_plan_ex -- the launches a flash_attention_ex() call with these arguments makes.  A bf16 problem may be split
- * in two (see "Precision of the softmax weights"): `early` describes the fp16-weights launch over the first
- * early->q_blocks query blocks of every head, `main` the launch over the remaining main->q_blocks; a launch that does not
- * happen has q_blocks = 0 and grid = 0.  lds_bytes is the launched instantiation's own figure (it depends on the engine, the
- * staging form and the output type).  flash_attention_plan() is this call with seqLenK = seqLen, flags = FA_FLAG_BF16_WEIGHTS
- * (one launch) and only `main` returned.  Either pointer may be NULL.
+ * flash_attention_plan_ex -- what a flash_attention_ex() call with these arguments launches.  A bf16 problem may be split in two
+ * ranges of query blocks (see "Precision of the softmax weights"): `early` describes the fp16-weights kernel over the first
+ * early->q_blocks query blocks of every head, `main` the bf16-weights kernel over the remaining main->q_blocks; a range that
+ * does not exist has q_blocks = 0 and grid = 0.  When both exist they run in ONE launch (every workgroup walks its main units,
+ * then its early units): both descriptions then carry that launch's grid and LDS size.  lds_bytes is the launched
+ * instantiation's own figure (it depends on the engine, the staging form and the output type).  flash_attention_plan() is
+ * this call with seqLenK = seqLen, flags = FA_FLAG_BF16_WEIGHTS (one range) and only `main` returned.  Either pointer may be NULL.
  */
 typedef struct fa_launch_plan_ex {
     fa_launch_plan launch;

@@ -77,6 +77,41 @@ static std::vector<Variant> make_variants() {
     constexpr int M = CAUSAL ? 0 : -1;   // production engine choice
     v.push_back({"production (16x16x32 non-causal, 32x32x16 causal), bf16 O", launch_cfg<ProdCfg<D, CAUSAL, T>>});
     v.push_back({"fp32 O (production)", launch_cfg<ProdCfg<D, CAUSAL, float>>, 4});
+    // the library's default call on a causal problem: two launches (include/flash_attention.h, "Precision of the softmax weights")
+    if constexpr (CAUSAL) {
+        v.push_back({"fp32 O, library default: fp16 weights on query blocks 0-3, bf16 weights on the rest (two launches)",
+                     [](const Params& p, int grid) {
+                         const int hp = std::min(p.nQ, 1024 / 256);
+                         Params a = p, b = p;
+                         a.qb0 = 0; a.nQ = hp; a.units = p.B * p.H * hp; a.cpx = (a.units + 7) / 8;
+                         b.qb0 = hp; b.nQ = p.nQ - hp; b.units = p.B * p.H * b.nQ; b.cpx = (b.units + 7) / 8;
+                         launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>(a, grid);
+                         if (b.nQ > 0) launch_cfg<ProdCfg<D, CAUSAL, float>>(b, grid);
+                     }, 4});
+        v.push_back({"fp32 O, library default in ONE launch (fwd_mfma_dual_kernel: late blocks, then early blocks)",
+                     [](const Params& p, int grid) {
+                         using CA = ProdCfg<D, CAUSAL, float>;
+                         using CB = P16Cfg<D, CAUSAL, float>;
+                         constexpr int lds = CA::LDS_BYTES > CB::LDS_BYTES ? CA::LDS_BYTES : CB::LDS_BYTES;
+                         static bool once = [] {
+                             HIP_CHECK(hipFuncSetAttribute((const void*)fwd_mfma_dual_kernel<CA, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                             return true;
+                         }();
+                         (void)once; (void)grid;
+                         const int hp = std::min(p.nQ, 1024 / 256);
+                         Params a = p, b = p;
+                         a.qb0 = hp; a.nQ = p.nQ - hp; a.units = p.B * p.H * a.nQ; a.cpx = (a.units + 7) / 8; a.jpx = std::min(a.cpx, g_cus / 8);
+                         b.qb0 = 0; b.nQ = hp; b.units = p.B * p.H * hp; b.cpx = (b.units + 7) / 8; b.jpx = std::min(b.cpx, g_cus / 8);
+                         hipLaunchKernelGGL((fwd_mfma_dual_kernel<CA, CB>), dim3(8 * std::max(a.jpx, b.jpx)), dim3(512), lds, nullptr, a, b);
+                     }, 4});
+        v.push_back({"fp32 O, fp16 weights on query blocks 0-3 ONLY (the first of the two launches)",
+                     [](const Params& p, int grid) {
+                         const int hp = std::min(p.nQ, 1024 / 256);
+                         Params a = p;
+                         a.qb0 = 0; a.nQ = hp; a.units = p.B * p.H * hp; a.cpx = (a.units + 7) / 8;
+                         launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>(a, grid);
+                     }, 4});
+    }
     v.push_back({"production STAMP, bf16 O", launch_cfg<ProdCfg<D, CAUSAL, T, 2, true>>});
     v.push_back({"production STAMP, fp32 O", launch_cfg<ProdCfg<D, CAUSAL, float, 2, true>>, 4});
     v.push_back({"the other engine", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = CAUSAL ? 1 : 0}>>});

@@ -13,7 +13,8 @@ model-layout views), output dtype and a score scale that sometimes forces the op
 LSE element-wise against a bound derived from the arithmetic the kernel is documented to do (DESIGN.md "Tolerance").
 
 The bound, term by term (ref_abs = sum_k p_k |v_k| = the oracle run on |V|; smax = largest |scale * score|):
-  O, bf16 / fp8 inputs   weights rounded to bf16 before P.V (2^-9 each, numerator and -- MFMA row sums -- denominator)  2^-8 ref_abs
+  O, bf16 / fp8 inputs   weights rounded to bf16 before P.V (half an ulp of 8 significant bits: <= 2^-8 relative each)  2^-8 ref_abs
+  O, bf16, no mask, no LSE request: the normaliser is the MFMA sum of the ROUNDED weights (computers16.hip.h)         + 2^-8 |ref|
   O, fp32 inputs         fp32 score noise through exp()                                              8 smax 2^-23 ref_abs
   O, fp8 inputs, extra   the fp8 MFMA's summation error is EPS_FP8 relative to the LARGEST product of the dot product (MEASURED:
                          tests/unit_kernels "MEASURE fp8 accumulation", profiles/r02_unit_kernels.log): score error <= EPS_FP8 * M,
@@ -126,6 +127,10 @@ def run_case(c):
             kvis = np.broadcast_to(kmax.max(-1, keepdims=True), qmax.shape)
         m_rowmax = scale * qmax * kvis                         # [B, H, Sq]: max over the visible keys of M[q][k]
         o_terms["fp8_accumulation"] = 2.0 * EPS_FP8 * float(m_rowmax.max()) * ref_abs
+    if dtype == torch.bfloat16 and not c["causal"] and not want_lse:
+        # the instantiation without the mask and without an LSE request normalises by the MFMA sum of the ROUNDED weights: the
+        # denominator carries the same 2^-9-per-weight rounding as the numerator (first exercised by the `lse` coin: round 3)
+        o_terms["bf16_weights_in_the_normaliser"] = 2.0 ** -8 * np.abs(ref)
     if c["out_dtype"] == torch.bfloat16:
         o_terms["bf16_output"] = 2.0 ** -8 * np.abs(ref)
     o_bound = sum(o_terms.values())

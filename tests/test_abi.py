@@ -131,8 +131,8 @@ def test_plan_ex_describes_both_launches():
     blocks of every head go to the fp16-weights kernel, the other 12 to the bf16-weights kernel; the flags move the split."""
     early, main = fa.plan_ex(8, 16, 4096, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, 0)
     assert (early["first_q_block"], early["q_blocks"], main["first_q_block"], main["q_blocks"]) == (0, 4, 4, 12)
-    assert early["grid"] == 256 and main["grid"] == 256 and early["threads"] == main["threads"] == 512
-    assert early["lds_bytes"] > 0 and main["lds_bytes"] == fa.plan(8, 16, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["lds_bytes"]
+    assert early["grid"] == 256 and main["grid"] == 256 and early["threads"] == main["threads"] == 512      # ONE launch runs both ranges
+    assert early["lds_bytes"] == main["lds_bytes"] >= fa.plan(8, 16, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["lds_bytes"]
     early, main = fa.plan_ex(8, 16, 4096, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, fa.FA_FLAG_BF16_WEIGHTS)
     assert (early["q_blocks"], early["grid"], main["q_blocks"]) == (0, 0, 16)
     early, main = fa.plan_ex(8, 16, 4096, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, fa.FA_FLAG_F16_WEIGHTS)
