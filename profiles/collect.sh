@@ -13,7 +13,8 @@ TAG=${1:?tag}
 WL=${2:-cfg2}
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-BENCH="python3 $REPO/bench.py --workload $WL --no-cpu-baseline --no-ceiling --steps 20 --warmup 5"
+# (--no-cfg4 --no-bf16-out: the trace then ends with the K timed steps of the workload itself: profiles/timed_region.py)
+BENCH="python3 $REPO/bench.py --workload $WL --no-cpu-baseline --no-ceiling --no-cfg4 --no-bf16-out --steps 20 --warmup 5"
 OUT=$REPO/gpurun_out
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o run -- $BENCH > $OUT/${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -o run -- $BENCH > $OUT/${TAG}_fetch.log 2>&1

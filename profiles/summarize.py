@@ -13,8 +13,9 @@ import sys
 csv.field_size_limit(1 << 30)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-ALGO = {"cfg2": 8 * 16 * 4096 * 128 * 2 * 4, "cfg2nc": 8 * 16 * 4096 * 128 * 2 * 4, "cfg1": 4 * 8 * 2048 * 64 * 2 * 4,
-        "cfg3": 1 * 16 * 16384 * 128 * (3 * 1 + 2)}
+# Q, K, V read once + O written once; bench.py's default output type is fp32 (4 bytes)
+ALGO = {"cfg2": 8 * 16 * 4096 * 128 * (3 * 2 + 4), "cfg2nc": 8 * 16 * 4096 * 128 * (3 * 2 + 4), "cfg1": 4 * 8 * 2048 * 64 * (3 * 2 + 4),
+        "cfg3": 1 * 16 * 16384 * 128 * (3 * 1 + 4)}
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import provenance  # noqa: E402
 
@@ -31,7 +32,7 @@ def counters(tag, suffix):
         return rows
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
-            if "fwd_mfma_kernel" in r["Kernel_Name"] or "fwd_f32_mfma" in r["Kernel_Name"]:
+            if "fwd_mfma_" in r["Kernel_Name"] or "fwd_f32_mfma" in r["Kernel_Name"]:   # (fwd_mfma_kernel, fwd_mfma_dual_kernel)
                 rows.setdefault(r["Counter_Name"], []).append((float(r["Counter_Value"]),
                                                                int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     return rows

@@ -14,7 +14,7 @@ path = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = []
 with open(path, newline="") as f:
     for r in csv.DictReader(f):
-        if "fwd_mfma_kernel" in r["Kernel_Name"] or "fwd_f32_mfma" in r["Kernel_Name"]:
+        if "fwd_mfma_" in r["Kernel_Name"] or "fwd_f32_mfma" in r["Kernel_Name"]:   # (fwd_mfma_kernel, fwd_mfma_dual_kernel)
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 rows.sort()
 dur = [x for _, x in rows]
