@@ -372,8 +372,13 @@ struct WaveCompute {
         zero(nxt);
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
+        if constexpr (C::PRIO_A) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
         slots_a<0>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        if constexpr (C::PRIO_A) {
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (C::STAMP) t_mid = cycle_stamp();
         slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();

@@ -51,6 +51,11 @@ struct KernelCfg {
     using OutT = OutT_;
     static constexpr int ESZ = ESZ_;                 // bytes per Q/K/V element: 2 = bf16, 1 = fp8 e4m3fn
     static constexpr bool STAMP = O.stamp, PAD = O.pad;
+    // Every wave runs phase A of a tile step (QK^T of the next tile: the K fragment reads, the tile's DMA pieces, most of the
+    // exponentials) at s_setprio 1 and phase B (P.V) at 0: of the two waves of a SIMD the one still in phase A outranks the one ahead
+    // of it.  +0.6 ... +1.3 % (causal and not, 21 / 15 interleaved rounds: profiles/r03_tune_j_phase_a_priority_*.log); static
+    // priorities for one half of the waves measured nothing (r03_tune_e_*)
+    static constexpr bool PRIO_A = true;
     // Cache policy of the output stores (utils.hip.h: store_global_b128): non-temporal under the causal mask -- O is written once and
     // never read, and every line it leaves in the XCD's L2 evicts K/V lines that the head's other query blocks are about to
     // re-read (causal, fp32 O: plain 1058, sc1 1073, nt 1076, sc0 sc1 1076 TFLOP/s; bf16 O +0.5 %; without the mask -0.3 %:
