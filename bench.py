@@ -183,12 +183,13 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
         Q, K, V = (torch.randn(shape, generator=g, device=dev, dtype=torch.float32).to(in_dtype) for _ in range(3))
         O = torch.empty(shape, device=dev, dtype=torch.bfloat16 if out_dtype == "bf16" else torch.float32)
     scale = 1.0 / d ** 0.5
+    wdt = None if (dry or esz != 2) else {"default": None, "bf16": torch.bfloat16, "f16": torch.float16}[args.weights]
 
     def step():
         if dry:
             time.sleep(2e-4)
         else:
-            fa.flash_attention(Q, K, V, O, scale=scale, is_causal=causal)
+            fa.flash_attention(Q, K, V, O, scale=scale, is_causal=causal, weights_dtype=wdt)
 
     def sync():
         if not dry:
@@ -266,7 +267,9 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
         "data": "synthetic",
         "config": {"workload": desc, "B": B, "H": H, "S": S, "d": d, "causal": causal,
                    "out_dtype": out_dtype, "heads_per_gpu": heads_local,
-                   "softmax_weights": "library default: fp16 on the query rows that see fewer than 1024 keys, bf16 elsewhere" if esz == 2 else "bf16",
+                   "softmax_weights": ({"default": "library default: fp16 on the query rows that see fewer than 1024 keys, bf16 elsewhere",
+                                        "bf16": "FA_FLAG_BF16_WEIGHTS: bf16 on every row", "f16": "FA_FLAG_F16_WEIGHTS: fp16 on every row"}[args.weights]
+                                       if esz == 2 else "bf16"),
                    "flop_convention": "2*B*H*S^2*d causal / 4*B*H*S^2*d non-causal",
                    "parallelism": f"batch x head shard over {world} GPU(s), no data-path collective"},
         "rccl_ranks": world,
@@ -292,7 +295,7 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
     if dry:
         rec["dry_run"] = True
     if want_parity and not dry:
-        rec["cpu_baseline"], rec["parity"] = cpu_baseline_and_parity(Q, K, V, O, S, d, causal)
+        rec["cpu_baseline"], rec["parity"] = cpu_baseline_and_parity(Q, K, V, O, S, d, causal, budget_s=args.cpu_budget_s)
         floor = PARITY_FLOOR[out_dtype]
         rec["parity"]["floor"] = floor
         if rec["parity"]["pass_frac_at_1e-3"] < floor:
@@ -327,6 +330,9 @@ def main():
     ap.add_argument("--no-bf16-out", action="store_true", help="skip the bf16-output sub-record")
     ap.add_argument("--out-dtype", default="f32", choices=["bf16", "f32"],
                     help="element type of O; f32 = the reference's float* O (kernels/FlashAttention.cuh:61)")
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="seconds of host-core time for the CPU baseline / parity sample (whole heads)")
+    ap.add_argument("--weights", default="default", choices=["default", "bf16", "f16"],
+                    help="softmax-weight precision (bf16 inputs): the library default, or one precision on every row (FA_FLAG_*_WEIGHTS)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: no launches, no measurements -- the line's structure only")
     args = ap.parse_args()
     if args.gpus < 1:
