@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 #include "../../include/flash_attention.h"
 #include "../helpers.hpp"
@@ -97,6 +98,33 @@ static int early_q_blocks(int S, int Sk, int d, bool causal, unsigned flags, int
     if (flags & FA_FLAG_F16_WEIGHTS) return nQ;
     if (Sk < FA_EARLY_KEYS) return nQ;
     return causal ? std::min(nQ, FA_EARLY_KEYS / q_block_rows) : 0;
+}
+
+// The snake schedule (kernel_bf16.hip.h: work_unit) gives every workgroup of an XCD group the same total when the list tiles its
+// rounds; when it does not, the slowest workgroup sets the launch's time.  Cost of one XCD group's walk over a causal list of `heads`
+// heads x nq query blocks starting at block qb0, in tile steps (+4 per unit for its prologue / epilogue): max over workgroups / mean.
+static double snake_imbalance(int64_t heads, int nq, int qb0, int S, int Sk, int qrows, int jpx_max) {
+    const int64_t units = heads * nq, cpx = (units + 7) / 8;
+    if (cpx > (1 << 16)) return 2.0;                       // (not worth a host-side walk: treated as unbalanced)
+    const int jpx = (int)std::min<int64_t>(cpx, jpx_max);
+    std::vector<double> tot(jpx, 0.0);
+    const int k_tiles = (Sk + 63) / 64;
+    for (int64_t idx = 0; idx < cpx && idx < units; ++idx) {
+        const int round = (int)(idx / jpx);
+        int j = (int)(idx % jpx);
+        if (round & 1) j = jpx - 1 - j;
+        const int qb = qb0 + nq - 1 - (int)(idx % nq);     // heaviest first
+        const int q_end = std::min(S, (qb + 1) * qrows);
+        tot[j] += std::min(k_tiles, (q_end + 63) / 64) + 4;
+    }
+    double mx = 0, sum = 0;
+    for (double t : tot) { mx = std::max(mx, t); sum += t; }
+    return sum > 0 ? mx * jpx / sum : 1.0;
+}
+// Causal default precision: walk two lists of their own (late blocks, early blocks) or the single kernel's list twice?  Two lists are
+// the faster form where the late list's schedule is balanced (fwd_mfma_dual_kernel).
+static bool two_lists_are_balanced(int64_t heads, int nQ_total, int hp, int S, int Sk, int qrows, int jpx_max) {
+    return snake_imbalance(heads, nQ_total - hp, hp, S, Sk, qrows, jpx_max) <= 1.02;
 }
 
 static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_dtype, float scale,
@@ -219,16 +247,22 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
     } else if (plan.kernel_id == 1) {   // bf16 inputs
         // Which query blocks take fp16 softmax weights (early_q_blocks): all with FA_FLAG_F16_WEIGHTS, none with
         // FA_FLAG_BF16_WEIGHTS, by default the rows that see few keys.  Both kinds present (a causal problem longer than
-        // FA_EARLY_KEYS): ONE launch whose workgroups walk the late blocks with the bf16-weights kernel, then the early blocks with
-        // the fp16-weights kernel (disjoint output rows).
+        // FA_EARLY_KEYS): ONE launch; every workgroup runs its late units with the bf16-weights kernel, then its early units with
+        // the fp16-weights kernel (disjoint output rows) -- from two unit lists of their own where that schedule is balanced (the
+        // faster form), else from the single kernel's list (kernel_bf16.hip.h: fwd_mfma_dual_kernel).
         const int hp = early_q_blocks(S, Sk, d, causal, flags, plan.q_block_rows);
         if (hp > 0 && hp < nQ_total && causal) {   // (without the mask early_q_blocks is all or nothing)
-            set_range(hp, nQ_total - hp, true);
-            const Params late = p;
-            const int grid_late = plan.grid;
-            set_range(0, hp, true);
-            plan.grid = std::max(plan.grid, grid_late);
-            e = launch_bf16_causal_dual(late, p, plan, d, o_dtype, st);
+            if (two_lists_are_balanced(B * H, nQ_total, hp, S, Sk, plan.q_block_rows, device_cus() / 8)) {
+                set_range(hp, nQ_total - hp, true);
+                const UnitList late = unit_list_of(p);
+                const int grid_late = plan.grid;
+                set_range(0, hp, true);
+                plan.grid = std::max(plan.grid, grid_late);
+                e = launch_bf16_causal_dual(p, late, unit_list_of(p), hp, plan, d, o_dtype, st);
+            } else {
+                set_range(0, nQ_total, true);
+                e = launch_bf16_causal_dual(p, unit_list_of(p), unit_list_of(p), hp, plan, d, o_dtype, st);
+            }
         } else if (hp > 0) {
             set_range(0, hp, true);
             e = launch_bf16_p16(p, plan, causal, d, o_dtype, st);
@@ -388,9 +422,10 @@ int flash_attention_plan_ex(int batchSize, int numHeads, int seqLenQ, int seqLen
     };
     fill(early, 0, hp, true);
     fill(main_, hp, nQ - hp, false);
-    if (hp > 0 && hp < nQ) {   // both ranges: one launch (fwd_mfma_dual_kernel) over the larger grid with the larger LDS carve-up
-        const int64_t ue = (int64_t)batchSize * numHeads * hp, um = (int64_t)batchSize * numHeads * (nQ - hp);
-        const int grid = (int)(8 * std::min<int64_t>((std::max(ue, um) + 7) / 8, fa::device_cus() / 8));
+    if (hp > 0 && hp < nQ) {   // both kinds: one launch (fwd_mfma_dual_kernel) with the larger LDS carve-up; the grid of its longest list
+        const bool two = fa::two_lists_are_balanced((int64_t)batchSize * numHeads, nQ, hp, seqLenQ, seqLenK, base.q_block_rows, fa::device_cus() / 8);
+        const int64_t units = (int64_t)batchSize * numHeads * (two ? std::max(hp, nQ - hp) : nQ);
+        const int grid = (int)(8 * std::min<int64_t>((units + 7) / 8, fa::device_cus() / 8));
         const int lds = fa::bf16_causal_dual_lds_bytes(dHead, o_dtype);
         if (early) { early->launch.grid = grid; early->launch.lds_bytes = lds; }
         if (main_) { main_->launch.grid = grid; main_->launch.lds_bytes = lds; }

@@ -201,7 +201,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
 // gets cost c in one round and (max+1-c) in the next -- a static schedule whose per-workgroup totals are equal when nQ divides
 // jpx.  With fewer units than CUs the grid is one workgroup per unit (a single round).  Pure speed choice: any placement is correct.
 template <class C>
-__device__ __forceinline__ bool work_unit(const Params& p, int round, int& g, int& qb) {
+__device__ __forceinline__ bool work_unit(const UnitList& p, int round, int& g, int& qb) {
     const int bid = blockIdx.x;
     int idx = bid >> 3;
     idx = round * p.jpx + ((round & 1) ? p.jpx - 1 - idx : idx);
@@ -241,14 +241,29 @@ struct UnitCtx {
     }
 };
 
-// Everything a workgroup does for one launch range: walk its units (work_unit) of configuration C.
-template <class C>
-__device__ __forceinline__ void run_units(const Params& p, lds_ptr smem) {
+// Which units of its list a walk takes: all of them (the single kernels), or -- in the launch that mixes two configurations
+// (fwd_mfma_dual_kernel) -- only the units of the query blocks qb >= hp (LATE) / qb < hp (EARLY).
+enum class Kind { ALL, LATE, EARLY };
+template <class C, Kind KIND>
+__device__ __forceinline__ bool next_unit(const UnitList& L, int& round, int& g, int& qb, int hp) {
+    if constexpr (KIND == Kind::ALL) return work_unit<C>(L, round, g, qb);
+    else {
+        while (work_unit<C>(L, round, g, qb)) {
+            if ((qb < hp) == (KIND == Kind::EARLY)) return true;
+            ++round;
+        }
+        return false;
+    }
+}
+
+// Everything a workgroup does with configuration C: walk the units of list L that are of its kind.
+template <class C, Kind KIND = Kind::ALL>
+__device__ __forceinline__ void run_units(const Params& p, const UnitList& L, lds_ptr smem, int hp = 0) {
     constexpr int D = C::D, ESZ = C::ESZ;
     using OutT = typename C::OutT;
 
     int g, qb, round = 0;
-    if (!work_unit<C>(p, 0, g, qb)) return;
+    if (!next_unit<C, KIND>(L, round, g, qb, hp)) return;
     unsigned long long t_kernel0 = 0;
     if constexpr (C::STAMP) t_kernel0 = cycle_stamp();
     const int lane = threadIdx.x & 63;
@@ -299,7 +314,8 @@ __device__ __forceinline__ void run_units(const Params& p, lds_ptr smem) {
         unsigned long long t_nx0 = 0;
         if constexpr (C::STAMP) t_nx0 = cycle_stamp();
         UnitCtx<C> nxt;
-        const bool more = work_unit<C>(p, ++round, g, qb);
+        ++round;
+        const bool more = next_unit<C, KIND>(L, round, g, qb, hp);
         if (more) {
             nxt.set(p, g, qb, wave);
             st.init(nxt.Kh, nxt.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
@@ -358,21 +374,30 @@ __device__ __forceinline__ void run_units(const Params& p, lds_ptr smem) {
 template <class C>
 __global__ __launch_bounds__(64 * C::NWAVES, 2) void fwd_mfma_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    run_units<C>(p, (lds_ptr)smem_raw);
+    run_units<C>(p, unit_list_of(p), (lds_ptr)smem_raw);
 }
 
-// Two launch ranges in ONE launch: every workgroup first walks its units of range A (configuration CA), then its units of range B
-// (CB).  This is how the library's default precision runs a causal bf16 problem: A = the bf16-weights kernel over the query blocks
-// whose rows see >= FA_EARLY_KEYS keys, B = the fp16-weights kernel over the first query blocks of every head -- as two launches
-// the small one pays a kernel boundary and both pay their own tail (0.5287 against 0.5163 ms for one kernel over all blocks,
-// profiles/r03_tune_e_split_cost_c.log); fused, a workgroup that finishes its A units early starts on its B units.
+// Two configurations in ONE launch.  This is how the library's default precision runs a causal bf16 problem: CA = the bf16-weights
+// kernel for the query blocks qb >= hp, CB = the fp16-weights kernel for the hp first blocks of every head (the rows that see fewer
+// than FA_EARLY_KEYS keys).  Every workgroup first runs its late units, then its early units (chained with cross-unit prefetch
+// inside each kind).  Which units are "its": the host picks one of two forms (csrc/FlashAttention.hip, dual_launch_form):
+//   two lists   la = the late blocks of all heads as a list of its own (qb0 = hp, nQ = blocks - hp), lb = the early blocks: each with
+//               its own snake schedule.  As fast as the single kernel when the late list's schedule is balanced (cfg2: 12 blocks per
+//               head, 6 whole rounds: 0.5237 against 0.5251 ms) -- and up to 54 % out of balance when it is not (64 heads at
+//               S = 8192: -10 %);
+//   one list    la = lb = the single kernel's list over all blocks: a workgroup skips the units of the other kind, so its total is
+//               what the single kernel gives it, whatever the shape (S = 8192: -2.9 %); but a workgroup that skips an early
+//               unit starts the next round's heads ahead of the others: -4.6 % at cfg2.
+// Measured alternatives (profiles/r03_tune_e_*, _f_*, _k_*, _n_*, r03_fetch_by_variant.txt): two launches, one per kind: +2.4 % time at
+// cfg2 (a 56 us launch of 512 tiny units, a kernel boundary, two tails); every unit dispatched to its kind in list order: half of
+// the workgroups alternate kinds at every unit boundary and lose the cross-unit prefetch there: -3.8 %.
 template <class CA, class CB>
-__global__ __launch_bounds__(64 * CA::NWAVES, 2) void fwd_mfma_dual_kernel(const Params pa, const Params pb) {
-    static_assert(CA::NWAVES == CB::NWAVES, "one workgroup shape");
+__global__ __launch_bounds__(64 * CA::NWAVES, 2) void fwd_mfma_dual_kernel(const Params p, const UnitList la, const UnitList lb, const int hp) {
+    static_assert(CA::NWAVES == CB::NWAVES && CA::CAUSAL == CB::CAUSAL && CA::QBLK == CB::QBLK, "one workgroup shape, one unit list");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    run_units<CA>(pa, (lds_ptr)smem_raw);
-    __syncthreads();   // (A's last epilogue regions and B's first ring slots alias: once per launch)
-    run_units<CB>(pb, (lds_ptr)smem_raw);
+    run_units<CA, Kind::LATE>(p, la, (lds_ptr)smem_raw, hp);
+    __syncthreads();   // (the two configurations carve the LDS differently: A's last epilogue regions against B's first ring slots)
+    run_units<CB, Kind::EARLY>(p, lb, (lds_ptr)smem_raw, hp);
 }
 
 }  // namespace fa

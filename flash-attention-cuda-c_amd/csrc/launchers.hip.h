@@ -33,9 +33,10 @@ hipError_t launch_bf16_d128(const Params& p, const fa_launch_plan& plan, bool ca
 hipError_t launch_bf16_d64(const Params& p, const fa_launch_plan& plan, bool causal, bool pad, int o_dtype, hipStream_t st);
 // bf16 inputs, fp16-weights precision option (d = 128 or 64 exactly)
 hipError_t launch_bf16_p16(const Params& p, const fa_launch_plan& plan, bool causal, int d, int o_dtype, hipStream_t st);
-// bf16 inputs, causal, default precision, d = 128 or 64 exactly: both kernels in one launch (pa: late query blocks, bf16 weights;
-// pb: early query blocks, fp16 weights)
-hipError_t launch_bf16_causal_dual(const Params& pa, const Params& pb, const fa_launch_plan& plan, int d, int o_dtype, hipStream_t st);
+// bf16 inputs, causal, default precision, d = 128 or 64 exactly: both kernels in one launch (the hp first query blocks of every head:
+// fp16 weights, unit list lb; the rest: bf16 weights, unit list la)
+hipError_t launch_bf16_causal_dual(const Params& p, const UnitList& la, const UnitList& lb, int hp, const fa_launch_plan& plan, int d, int o_dtype,
+                                   hipStream_t st);
 int bf16_causal_dual_lds_bytes(int d, int o_dtype);
 // fp8 e4m3fn inputs (always the D = 128 instantiation)
 hipError_t launch_fp8_d128(const Params& p, const fa_launch_plan& plan, bool causal, bool pad, int o_dtype, hipStream_t st);

@@ -51,6 +51,13 @@ struct Params {
     unsigned long long* dbg;  // diagnostic builds only (tests/fa_tune): per-wave segment cycle sums
 };
 
+// The unit list a workgroup walks (kernel_bf16.hip.h: work_unit): the query blocks qb0 .. qb0 + nQ - 1 of every head.  The single
+// kernels take it from Params; the launch that mixes two configurations takes two of them beside ONE Params.
+struct UnitList {
+    int nQ, qb0, units, cpx, jpx;
+};
+__host__ __device__ inline UnitList unit_list_of(const Params& p) { return UnitList{p.nQ, p.qb0, p.units, p.cpx, p.jpx}; }
+
 // Workgroup -> (head, query block).  Blocks b and b+8 share an XCD (round-robin dispatch), so
 // giving each XCD group a CONTIGUOUS range of units keeps all query blocks of a head -- which
 // re-read the same K/V -- on one XCD's L2.  Pure speed choice: any placement is correct.

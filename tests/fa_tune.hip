@@ -88,22 +88,27 @@ static std::vector<Variant> make_variants() {
                          launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>(a, grid);
                          if (b.nQ > 0) launch_cfg<ProdCfg<D, CAUSAL, float>>(b, grid);
                      }, 4});
-        v.push_back({"fp32 O, library default in ONE launch (fwd_mfma_dual_kernel: late blocks, then early blocks)",
-                     [](const Params& p, int grid) {
-                         using CA = ProdCfg<D, CAUSAL, float>;
-                         using CB = P16Cfg<D, CAUSAL, float>;
-                         constexpr int lds = CA::LDS_BYTES > CB::LDS_BYTES ? CA::LDS_BYTES : CB::LDS_BYTES;
-                         static bool once = [] {
-                             HIP_CHECK(hipFuncSetAttribute((const void*)fwd_mfma_dual_kernel<CA, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                             return true;
-                         }();
-                         (void)once; (void)grid;
-                         const int hp = std::min(p.nQ, 1024 / 256);
-                         Params a = p, b = p;
-                         a.qb0 = hp; a.nQ = p.nQ - hp; a.units = p.B * p.H * a.nQ; a.cpx = (a.units + 7) / 8; a.jpx = std::min(a.cpx, g_cus / 8);
-                         b.qb0 = 0; b.nQ = hp; b.units = p.B * p.H * hp; b.cpx = (b.units + 7) / 8; b.jpx = std::min(b.cpx, g_cus / 8);
-                         hipLaunchKernelGGL((fwd_mfma_dual_kernel<CA, CB>), dim3(8 * std::max(a.jpx, b.jpx)), dim3(512), lds, nullptr, a, b);
-                     }, 4});
+        auto dual = [](const Params& p, bool two_lists) {
+            using CA = ProdCfg<D, CAUSAL, float>;
+            using CB = P16Cfg<D, CAUSAL, float>;
+            constexpr int lds = CA::LDS_BYTES > CB::LDS_BYTES ? CA::LDS_BYTES : CB::LDS_BYTES;
+            static bool once = [] {
+                HIP_CHECK(hipFuncSetAttribute((const void*)fwd_mfma_dual_kernel<CA, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                return true;
+            }();
+            (void)once;
+            const int hp = std::min(p.nQ, 1024 / 256);
+            Params a = p, b = p;
+            if (two_lists) {
+                a.qb0 = hp; a.nQ = p.nQ - hp; a.units = p.B * p.H * a.nQ; a.cpx = (a.units + 7) / 8;
+                b.qb0 = 0; b.nQ = hp; b.units = p.B * p.H * hp; b.cpx = (b.units + 7) / 8;
+            }
+            a.jpx = std::min(a.cpx, g_cus / 8);
+            b.jpx = std::min(b.cpx, g_cus / 8);
+            hipLaunchKernelGGL((fwd_mfma_dual_kernel<CA, CB>), dim3(8 * std::max(a.jpx, b.jpx)), dim3(512), lds, nullptr, p, unit_list_of(a), unit_list_of(b), hp);
+        };
+        v.push_back({"fp32 O, library default in ONE launch, two unit lists (late blocks, early blocks)", [dual](const Params& p, int) { dual(p, true); }, 4});
+        v.push_back({"fp32 O, library default in ONE launch, the single kernel's list walked twice", [dual](const Params& p, int) { dual(p, false); }, 4});
         v.push_back({"fp32 O, fp16 weights on query blocks 0-3 ONLY (the first of the two launches)",
                      [](const Params& p, int grid) {
                          const int hp = std::min(p.nQ, 1024 / 256);
