@@ -257,7 +257,8 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
     value = flops_of(total_heads, S, d, causal) / (ms_per_step * 1e-3) / 1e12
     achieved = flops_of(heads_local, S, d, causal) / (kernel_ms_max * 1e-3) / 1e12
     bound, peak, why, issue_bound = bound_for(workload)
-    traffic, prov = measured_traffic(workload) if world == 1 and out_dtype == args.out_dtype else (None, None)
+    # (the committed PMC run is of the default call: fp32 output, default weight precision)
+    traffic, prov = measured_traffic(workload) if world == 1 and out_dtype == args.out_dtype == "f32" and args.weights == "default" else (None, None)
     algo_bytes = heads_local * S * d * (3 * esz + osz)
     rec = {
         "metric": METRIC if workload.startswith("cfg2") else f"fwd attention TFLOP/s/GPU ({desc}) + % MFMA peak",
