@@ -46,7 +46,7 @@ class FaLaunchPlan(ctypes.Structure):
 
 
 class FaLaunchPlanEx(ctypes.Structure):
-    _fields_ = [("launch", FaLaunchPlan), ("q_blocks", ctypes.c_int), ("first_q_block", ctypes.c_int)]
+    _fields_ = [("launch", FaLaunchPlan), ("q_blocks", ctypes.c_int), ("first_q_block", ctypes.c_int), ("unit_lists", ctypes.c_int)]
 
 
 class FlashAttentionError(RuntimeError):
@@ -150,7 +150,7 @@ def plan_ex(batchSize, numHeads, seqLenQ, seqLenK, dHead, is_causal=False, dtype
     e, m = FaLaunchPlanEx(), FaLaunchPlanEx()
     _check(lib().flash_attention_plan_ex(batchSize, numHeads, seqLenQ, seqLenK, dHead, bool(is_causal), dtype, o_dtype, flags,
                                          ctypes.byref(e), ctypes.byref(m)))
-    conv = lambda x: dict({k: getattr(x.launch, k) for k, _ in FaLaunchPlan._fields_}, q_blocks=x.q_blocks, first_q_block=x.first_q_block)
+    conv = lambda x: dict({k: getattr(x.launch, k) for k, _ in FaLaunchPlan._fields_}, q_blocks=x.q_blocks, first_q_block=x.first_q_block, unit_lists=x.unit_lists)
     return conv(e), conv(m)
 
 

@@ -414,6 +414,7 @@ int flash_attention_plan_ex(int batchSize, int numHeads, int seqLenQ, int seqLen
         out->launch = base;
         out->first_q_block = qb0;
         out->q_blocks = nq;
+        out->unit_lists = 0;
         const int64_t units = (int64_t)batchSize * numHeads * nq;
         if (nq == 0) out->launch.grid = 0;
         else if (base.kernel_id == 1 || base.kernel_id == 2) out->launch.grid = (int)(8 * std::min<int64_t>((units + 7) / 8, fa::device_cus() / 8));
@@ -427,8 +428,8 @@ int flash_attention_plan_ex(int batchSize, int numHeads, int seqLenQ, int seqLen
         const int64_t units = (int64_t)batchSize * numHeads * (two ? std::max(hp, nQ - hp) : nQ);
         const int grid = (int)(8 * std::min<int64_t>((units + 7) / 8, fa::device_cus() / 8));
         const int lds = fa::bf16_causal_dual_lds_bytes(dHead, o_dtype);
-        if (early) { early->launch.grid = grid; early->launch.lds_bytes = lds; }
-        if (main_) { main_->launch.grid = grid; main_->launch.lds_bytes = lds; }
+        if (early) { early->launch.grid = grid; early->launch.lds_bytes = lds; early->unit_lists = two ? 2 : 1; }
+        if (main_) { main_->launch.grid = grid; main_->launch.lds_bytes = lds; main_->unit_lists = two ? 2 : 1; }
     }
     return FA_OK;
 }

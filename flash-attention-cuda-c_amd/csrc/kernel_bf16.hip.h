@@ -41,7 +41,7 @@ struct Opt {
     int sum_mfma = -1;           // 16x16x32 engine: row sums from ONES.P^T MFMAs (sums the bf16-rounded weights) instead of one v_add_f32
                                  // per score.  -1: on (the library turns it off in the kernels that return the LSE)
     bool p_f16 = false;          // 16x16x32 engine: weights rounded to fp16 (11 significant bits) instead of bf16 (8), V staged as fp16, P.V
-                                 // on v_mfma_f32_16x16x32_f16: the precision option behind FA_FLAG_F16_WEIGHTS (needs |V| <= 65504)
+                                 // on v_mfma_f32_16x16x32_f16 (needs |V| <= 65504): FA_FLAG_F16_WEIGHTS, and by default the query blocks whose rows see few keys
 };
 
 template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, Opt O = Opt{}>
@@ -264,8 +264,8 @@ __device__ __forceinline__ void run_units(const Params& p, const UnitList& L, ld
 
     int g, qb, round = 0;
     if (!next_unit<C, KIND>(L, round, g, qb, hp)) return;
-    unsigned long long t_kernel0 = 0;
-    if constexpr (C::STAMP) t_kernel0 = cycle_stamp();
+    unsigned long long t_kernel0 = 0, t_real0 = 0;
+    if constexpr (C::STAMP) { t_real0 = realtime_stamp(); t_kernel0 = cycle_stamp(); }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = p.S, Sk = p.Sk;
@@ -363,6 +363,10 @@ __device__ __forceinline__ void run_units(const Params& p, const UnitList& L, ld
         const unsigned long long t_end = cycle_stamp();
         acc[14] = t_end - t_tail0;
         acc[0] = t_end - t_kernel0;                        // whole workgroup lifetime of this wave
+        const unsigned long long t_real1 = realtime_stamp();
+        acc[17] = t_real1 - t_real0;                       // ... and in ticks of the constant 100 MHz counter (-> the core clock it ran at),
+        acc[18] = t_real0;                                 // whose absolute values place the workgroups of a launch against each other
+        acc[19] = t_real1;
         if (lane == 0 && p.dbg) {
             acc[11] = 1;   // (rows of waves that do not exist stay 0)
 #pragma unroll

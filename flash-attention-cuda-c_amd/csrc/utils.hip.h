@@ -170,6 +170,14 @@ __device__ __forceinline__ u32x4 fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
 }
 
 // s_memtime stamp for diagnostic builds: one asm statement with its own wait, fenced (guide: In-kernel stamps).
+// the constant 100 MHz counter: with cycle_stamp() around the same stretch it gives the core clock the stretch ran at
+__device__ __forceinline__ unsigned long long realtime_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
 __device__ __forceinline__ unsigned long long cycle_stamp() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);

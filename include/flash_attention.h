@@ -241,8 +241,11 @@ int flash_attention_plan(int batchSize, int numHeads, int seqLen, int dHead, boo
  */
 typedef struct fa_launch_plan_ex {
     fa_launch_plan launch;
-    int q_blocks;        /* query blocks of every head this launch covers */
+    int q_blocks;        /* query blocks of every head this range covers */
     int first_q_block;   /* ... starting at this one */
+    int unit_lists;      /* both ranges in one launch: 2 = each range walks a (head, query block) list of its own -- chosen where that
+                            schedule is balanced, the faster form --, 1 = both walk the list over all query blocks, each skipping the
+                            other's units (balanced for every shape); 0 = this is the only range */
 } fa_launch_plan_ex;
 
 int flash_attention_plan_ex(int batchSize, int numHeads, int seqLenQ, int seqLenK, int dHead, bool is_causal,

@@ -316,6 +316,31 @@ int main(int argc, char** argv) {
                     printf("    workgroup lifetimes (%d workgroups): min %.0f  mean %.0f  max %.0f cycles  (max/mean %.3f); per XCD mean:", cnt, mn, sum / cnt, mx, mx / (sum / cnt));
                     for (int x = 0; x < 8; ++x) printf(" %.0f", xcnt[x] ? xsum[x] / xcnt[x] : 0.0);
                     printf("\n");
+                    // the same lifetimes on the constant 100 MHz counter: the core clock each XCD ran at, and when its workgroups ended
+                    double ticks = 0, s0 = 1e30, s1 = 0, e0 = 1e30, e1 = 0;
+                    for (size_t g = 0; g < (size_t)grid; ++g) {
+                        const double a = (double)h[(g * 8) * 24 + 18], b = (double)h[(g * 8) * 24 + 19];
+                        if (b <= 0) continue;
+                        ticks += (double)h[(g * 8) * 24 + 17];
+                        s0 = std::min(s0, a); s1 = std::max(s1, a); e0 = std::min(e0, b); e1 = std::max(e1, b);
+                    }
+                    if (ticks > 0) {
+                        printf("    per XCD (workgroup index & 7): mean lifetime us / clock GHz / last end after the first start, us:");
+                        for (int x = 0; x < 8; ++x) {
+                            double tk = 0, cy = 0, le = 0; int n = 0;
+                            for (size_t g = x; g < (size_t)grid; g += 8) {
+                                const double b = (double)h[(g * 8) * 24 + 19];
+                                if (b <= 0) continue;
+                                tk += (double)h[(g * 8) * 24 + 17]; cy += (double)h[(g * 8) * 24 + 0]; le = std::max(le, b); ++n;
+                            }
+                            if (n) printf("  %.1f/%.3f/%.1f", tk / n * 0.01, cy / tk * 0.1, (le - s0) * 0.01);
+                        }
+                        printf("\n");
+                        printf("    last launch, 100 MHz counter: first workgroup start -> last workgroup end %.1f us; starts spread over %.1f us, ends over %.1f us\n",
+                               (e1 - s0) * 0.01, (s1 - s0) * 0.01, (e1 - e0) * 0.01);
+                        printf("    core clock over the workgroup lifetimes (s_memtime / s_memrealtime at 100 MHz): %.3f GHz; mean lifetime %.1f us\n",
+                               sum / ticks * 0.1, ticks / cnt * 0.01);
+                    }
                 }
             }
             const double loop = (seg[1] + seg[2] + seg[3] + seg[5]) / nw, tot = seg[0] / nw;
