@@ -56,6 +56,6 @@ asm: $(KSRC) $(KHDR)
 	mkdir -p build && $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/inst_bf16_d128.s $(PKG)/csrc/inst_bf16_d128.hip
 
 clean:
-	rm -f $(LIB) $(PKG)/fa_main tests/fa_test tests/fa_tune tests/unit_kernels tests/micro/simd_mix tests/micro/valu_rates oracle/liboracle_attention.so
+	rm -f $(LIB) $(PKG)/fa_main tests/fa_test tests/fa_tune tests/unit_kernels tests/micro/simd_mix tests/micro/valu_rates tests/micro/atomic_latency oracle/liboracle_attention.so
 	rm -rf build
 .PHONY: all lib tune oracle clean asm
