@@ -124,7 +124,14 @@ static double snake_imbalance(int64_t heads, int nq, int qb0, int S, int Sk, int
 // Causal default precision: walk two lists of their own (late blocks, early blocks) or the single kernel's list twice?  Two lists are
 // the faster form where the late list's schedule is balanced (fwd_mfma_dual_kernel).
 static bool two_lists_are_balanced(int64_t heads, int nQ_total, int hp, int S, int Sk, int qrows, int jpx_max) {
-    return snake_imbalance(heads, nQ_total - hp, hp, S, Sk, qrows, jpx_max) <= 1.02;
+    // (the walk is up to 64 Ki steps: a caller that repeats a shape -- every caller in practice -- pays for it once per thread)
+    struct Memo { int64_t heads; int nQ, hp, S, Sk, qrows, jpx; bool ok; bool valid; };
+    static thread_local Memo m{};
+    if (m.valid && m.heads == heads && m.nQ == nQ_total && m.hp == hp && m.S == S && m.Sk == Sk && m.qrows == qrows && m.jpx == jpx_max)
+        return m.ok;
+    const bool ok = snake_imbalance(heads, nQ_total - hp, hp, S, Sk, qrows, jpx_max) <= 1.02;
+    m = Memo{heads, nQ_total, hp, S, Sk, qrows, jpx_max, ok, true};
+    return ok;
 }
 
 static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_dtype, float scale,
