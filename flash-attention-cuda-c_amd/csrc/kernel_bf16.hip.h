@@ -40,6 +40,8 @@ struct Opt {
                                  // a higher clock on that shape (power).  -1: on for bf16 inputs
     int sum_mfma = -1;           // 16x16x32 engine: row sums from ONES.P^T MFMAs (sums the bf16-rounded weights) instead of one v_add_f32
                                  // per score.  -1: on (the library turns it off in the kernels that return the LSE)
+    int waves = 8;               // waves per workgroup.  4: 128-row units, two workgroups per CU where the LDS allows (d = 64): the small causal
+                                 // problems with one 256-row unit per CU or fewer (fwd_mfma_pair_kernel)
     bool p_f16 = false;          // 16x16x32 engine: weights rounded to fp16 (11 significant bits) instead of bf16 (8), V staged as fp16, P.V
                                  // on v_mfma_f32_16x16x32_f16 (needs |V| <= 65504): FA_FLAG_F16_WEIGHTS, and by default the query blocks whose rows see few keys
 };
@@ -77,11 +79,12 @@ struct KernelCfg {
     // unit's tile 0 lands there while the epilogue runs
     static constexpr bool DMA = ESZ_ == 2 && !O.pad && !O.p_f16;
     // fp8 inputs: K alone by LDS-DMA (V is widened to bf16 on its way into LDS and keeps the register path): HybridStageFp8
-    static constexpr bool DMA_K8 = ESZ_ == 1 && D_ == 128 && !O.pad;
+    static constexpr bool DMA_K8 = ESZ_ == 1 && D_ == 128 && !O.pad && O.waves == 8;
     static constexpr int NPRE = 4;                   // K fragments in flight ahead of their MFMA
     static constexpr int VPRE = 2;                   // V^T fragments in flight ahead of their MFMA
     static constexpr int THR = 8;                    // lazy-rescale threshold of the tracked pass, log2 units
-    static constexpr int NWAVES = 8;                 // waves per workgroup, two per SIMD, 32 query rows each
+    static constexpr int NWAVES = O.waves;           // waves per workgroup (8: two per SIMD; 4: one per SIMD and workgroup), 32 query rows each
+    static_assert(NWAVES == 8 || NWAVES == 4, "8 or 4 waves");
     static constexpr int QBLK = 32 * NWAVES;         // query rows of a unit
     static constexpr int RING = 3;                   // LDS ring slots: tile t+2 is staged in iteration t
     static constexpr int RING_BYTES = RING * TileGeom<D_, ESZ_>::SLOT;
@@ -243,11 +246,15 @@ struct UnitCtx {
 
 // Which units of its list a walk takes: all of them (the single kernels), or -- in the launch that mixes two configurations
 // (fwd_mfma_dual_kernel) -- only the units of the query blocks qb >= hp (LATE) / qb < hp (EARLY).
-enum class Kind { ALL, LATE, EARLY };
+enum class Kind { ALL, LATE, EARLY, ONE };   // ONE: the single unit (head L.units, query block L.qb0) -- fwd_mfma_pair_kernel
 template <class C, Kind KIND>
 __device__ __forceinline__ bool next_unit(const UnitList& L, int& round, int& g, int& qb, int hp) {
     if constexpr (KIND == Kind::ALL) return work_unit<C>(L, round, g, qb);
-    else {
+    else if constexpr (KIND == Kind::ONE) {
+        g = L.units;
+        qb = L.qb0;
+        return round == 0;
+    } else {
         while (work_unit<C>(L, round, g, qb)) {
             if ((qb < hp) == (KIND == Kind::EARLY)) return true;
             ++round;
@@ -402,6 +409,29 @@ __global__ __launch_bounds__(64 * CA::NWAVES, 2) void fwd_mfma_dual_kernel(const
     run_units<CA, Kind::LATE>(p, la, (lds_ptr)smem_raw, hp);
     __syncthreads();   // (the two configurations carve the LDS differently: A's last epilogue regions against B's first ring slots)
     run_units<CB, Kind::EARLY>(p, lb, (lds_ptr)smem_raw, hp);
+}
+
+// Small causal problems: ONE unit per workgroup, 128 query rows, four waves, two workgroups per CU.  With one 256-row unit per CU (or
+// fewer) the launch lasts as long as its heaviest unit while the counted work is the mean -- 4.5 / 8 at BASELINE cfg1.  Here the units
+// are half as tall, every CU gets two of them, and the two are the heaviest and the lightest left of its XCD group's heads: workgroups
+// are dispatched in index order, one per CU and round, so x + 8 s (s < jpx) and x + 8 (jpx + s) share a CU; the first takes the
+// s-th heaviest unit of group x (causal: the highest query blocks of its heads), the second the s-th lightest.  Blocks below hp
+// (the rows that see fewer than FA_EARLY_KEYS keys) run configuration CB, the others CA (include/flash_attention.h, "Precision ...").
+template <class CA, class CB>
+__global__ __launch_bounds__(64 * CA::NWAVES, 2) void fwd_mfma_pair_kernel(const Params p, const int hp, const int jpx) {
+    static_assert(CA::NWAVES == 4 && CB::NWAVES == 4 && CA::CAUSAL && CB::CAUSAL, "the pairing is by causal weight");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
+    const int heads = p.B * p.H, hpx = (heads + 7) / 8;
+    const int h0 = x * hpx, nh = min(hpx, heads - h0);
+    if (nh <= 0) return;
+    const int n = nh * p.nQ;                                   // this group's units, heaviest first: block nQ-1 of its heads, nQ-2, ...
+    const int idx = s < jpx ? s : n - 1 - (s - jpx);
+    if (idx >= n || (s >= jpx && idx < jpx)) return;
+    const int blk = idx / nh;
+    const UnitList one{p.nQ, p.nQ - 1 - blk, h0 + (idx - blk * nh), 0, 0};
+    if (one.qb0 < hp) run_units<CB, Kind::ONE>(p, one, (lds_ptr)smem_raw, hp);
+    else run_units<CA, Kind::ONE>(p, one, (lds_ptr)smem_raw, hp);
 }
 
 }  // namespace fa

@@ -117,6 +117,26 @@ static std::vector<Variant> make_variants() {
                          launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>(a, grid);
                      }, 4});
     }
+    if constexpr (CAUSAL && D == 64) {
+        // small causal problems: 128-row units, one per workgroup, two workgroups per CU paired heavy + light (fwd_mfma_pair_kernel)
+        auto pair = [](const Params& p, unsigned flags) {
+            using CA = KernelCfg<D, true, float, 2, Opt{.m16 = 0, .waves = 4}>;
+            using CB = KernelCfg<D, true, float, 2, Opt{.sum_mfma = 0, .waves = 4, .p_f16 = true}>;
+            constexpr int lds = CA::LDS_BYTES > CB::LDS_BYTES ? CA::LDS_BYTES : CB::LDS_BYTES;
+            static bool once = [] {
+                HIP_CHECK(hipFuncSetAttribute((const void*)fwd_mfma_pair_kernel<CA, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                return true;
+            }();
+            (void)once;
+            Params q = p;
+            q.nQ = (p.S + 127) / 128;
+            const int hp = flags == 2 ? 0 : std::min(q.nQ, 1024 / 128);
+            const int jpx = g_cus / 8;
+            hipLaunchKernelGGL((fwd_mfma_pair_kernel<CA, CB>), dim3(8 * 2 * jpx), dim3(256), lds, nullptr, q, hp, jpx);
+        };
+        v.push_back({"fp32 O, PAIR kernel: 128-row units, 2 workgroups per CU, default precision", [pair](const Params& p, int) { pair(p, 0); }, 4});
+        v.push_back({"fp32 O, PAIR kernel: 128-row units, 2 workgroups per CU, bf16 weights", [pair](const Params& p, int) { pair(p, 2); }, 4});
+    }
     v.push_back({"production STAMP, bf16 O", launch_cfg<ProdCfg<D, CAUSAL, T, 2, true>>});
     v.push_back({"production STAMP, fp32 O", launch_cfg<ProdCfg<D, CAUSAL, float, 2, true>>, 4});
     v.push_back({"the other engine", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = CAUSAL ? 1 : 0}>>});
