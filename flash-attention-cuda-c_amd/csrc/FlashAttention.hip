@@ -134,6 +134,16 @@ static bool two_lists_are_balanced(int64_t heads, int nQ_total, int hp, int S, i
     return ok;
 }
 
+// Small causal problems at D = 64 take the pair kernel (kernel_bf16.hip.h: fwd_mfma_pair_kernel): at most one 256-row unit per CU --
+// where the launch would last as long as its heaviest unit -- and every XCD group's 128-row units fit its two workgroups per CU.
+static bool pair_kernel_applies(int B, int H, int S, int d, bool causal, int dtype, float scale) {
+    if (!(dtype == FA_DTYPE_BF16 && d == 64 && causal && scale > 0.f)) return false;
+    const int64_t heads = (int64_t)B * H;
+    const int cus = device_cus(), jpx = cus / 8;
+    if (heads * getNumCta(S, 256) > cus) return false;
+    return ((heads + 7) / 8) * getNumCta(S, 128) <= 2 * jpx;
+}
+
 static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_dtype, float scale,
                      fa_launch_plan* plan) {
     // bf16: d in {64,128} natively; any other multiple of 8 up to 128 runs the next larger instantiation with its
@@ -168,6 +178,13 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
         const int nQ = getNumCta(S, plan->q_block_rows);
         const int64_t units = (int64_t)B * H * nQ;
         plan->grid = (int)(8 * std::min<int64_t>((units + 7) / 8, device_cus() / 8));
+        if (mfma_bf16 && pair_kernel_applies(B, H, S, d, causal, dtype, scale)) {
+            // 128-row units, one per workgroup of four waves, two workgroups per CU (grid = 16 per XCD-group workgroup slot pair)
+            plan->q_block_rows = 128;
+            plan->threads = 256;
+            plan->lds_bytes = bf16_causal_pair_lds_bytes(o_dtype);
+            plan->grid = 16 * (device_cus() / 8);
+        }
     } else {
         plan->kernel_id = 0;
         plan->q_block_rows = GenericCfg::BQ;
@@ -258,7 +275,14 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
         // the fp16-weights kernel (disjoint output rows) -- from two unit lists of their own where that schedule is balanced (the
         // faster form), else from the single kernel's list (kernel_bf16.hip.h: fwd_mfma_dual_kernel).
         const int hp = early_q_blocks(S, Sk, d, causal, flags, plan.q_block_rows);
-        if (hp > 0 && hp < nQ_total && causal) {   // (without the mask early_q_blocks is all or nothing)
+        if (pair_kernel_applies(B, H, S, d, causal, dtype, scale)) {   // (make_plan chose 128-row blocks, 256 threads, its grid)
+            p.qb0 = 0;
+            p.nQ = nQ_total;
+            p.units = B * H * nQ_total;
+            p.cpx = (p.units + 7) / 8;
+            p.jpx = plan.grid / 16;
+            e = launch_bf16_causal_pair(p, hp, p.jpx, plan, o_dtype, st);
+        } else if (hp > 0 && hp < nQ_total && causal) {   // (without the mask early_q_blocks is all or nothing)
             if (two_lists_are_balanced(B * H, nQ_total, hp, S, Sk, plan.q_block_rows, device_cus() / 8)) {
                 set_range(hp, nQ_total - hp, true);
                 const UnitList late = unit_list_of(p);
@@ -430,7 +454,10 @@ int flash_attention_plan_ex(int batchSize, int numHeads, int seqLenQ, int seqLen
     };
     fill(early, 0, hp, true);
     fill(main_, hp, nQ - hp, false);
-    if (hp > 0 && hp < nQ) {   // both kinds: one launch (fwd_mfma_dual_kernel) with the larger LDS carve-up; the grid of its longest list
+    if (base.kernel_id == 1 && base.threads == 256) {   // the pair kernel: one launch whatever the ranges, its own grid and LDS size
+        if (early && hp > 0) early->launch = base;
+        if (main_ && nQ - hp > 0) main_->launch = base;
+    } else if (hp > 0 && hp < nQ) {   // both kinds: one launch (fwd_mfma_dual_kernel) with the larger LDS carve-up; the grid of its longest list
         const bool two = fa::two_lists_are_balanced((int64_t)batchSize * numHeads, nQ, hp, seqLenQ, seqLenK, base.q_block_rows, fa::device_cus() / 8);
         const int64_t units = (int64_t)batchSize * numHeads * (two ? std::max(hp, nQ - hp) : nQ);
         const int grid = (int)(8 * std::min<int64_t>((units + 7) / 8, fa::device_cus() / 8));

@@ -75,7 +75,7 @@ enum {
  * not (the first rows of a causal problem: measured 1.3 x the tolerance at 64 visible keys, 0.9 x at 256, 0.74 x at 1024).
  *
  *   default (flags = 0)    rows that can see fewer than FA_EARLY_KEYS keys take fp16 weights, all others bf16 weights: under the
- *                          causal mask the query rows q < FA_EARLY_KEYS of every head (whole 256-row query blocks; the same
+ *                          causal mask the query rows q < FA_EARLY_KEYS of every head (whole query blocks; the same
  *                          launch runs both kernels, each workgroup first its late then its early blocks), and every row when
  *                          seqLenK < FA_EARLY_KEYS.  Meets the stated tolerance on every element with fp32 output; costs
  *                          ~1 % at seqLen 4096.
@@ -219,7 +219,8 @@ int flash_attention_sharded(int nDevices, const int* deviceIds,
  * Fills the tile sizes and grid the library will use for this problem; returns 0 or FA_ERR_*.
  */
 typedef struct fa_launch_plan {
-    int q_block_rows;    /* Br: query rows per workgroup          (helpers.hpp:8-19)  */
+    int q_block_rows;    /* Br: query rows per workgroup          (helpers.hpp:8-19); 256 on the MFMA paths' persistent kernels, 128 (and
+                            threads = 256, two workgroups per CU) for small causal bf16 problems at dHead 64: the pair kernel */
     int kv_block_rows;   /* Bc: keys per inner-loop tile           (helpers.hpp:21-30) */
     int threads;         /* threads per workgroup                  (tests/main.cu:52)  */
     int grid;            /* number of workgroups                   (helpers.hpp:33-36) */

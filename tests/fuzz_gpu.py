@@ -154,11 +154,13 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     fails, t0, kinds = 0, time.time(), {}
-    worst_fp8_lse = 0.0
+    worst_fp8_lse, pair_cases = 0.0, 0
     for c in draw_cases(args.seed, args.cases):
         r = run_case(c)
         key = (str(c["dtype"]).split(".")[-1], c["d"] in (64, 128))
         kinds[key] = kinds.get(key, 0) + 1
+        if c["dtype"] == torch.bfloat16 and fa.plan(c["B"], c["H"], c["Sq"], c["d"], c["causal"], fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["threads"] == 256:
+            pair_cases += 1      # (the small-causal-problem kernel at d = 64: fwd_mfma_pair_kernel)
         if c["dtype"] == FP8:
             worst_fp8_lse = max(worst_fp8_lse, r["worst_l"])
         if r["bad_o"] or r["bad_l"]:
@@ -166,7 +168,7 @@ def main():
             print(f"FAIL {describe(c)}: O bad {r['bad_o']}/{r['n_o']} max err {r['o_err_max']:.3e} (worst err/bound {r['worst_o']:.2f}), "
                   f"LSE bad {r['bad_l']} (worst err/bound {r['worst_l']:.2f})", flush=True)
     print(f"{args.cases} cases, {fails} failed, {time.time() - t0:.1f} s, seed {args.seed}; fp8 LSE worst err/bound {worst_fp8_lse:.3f}; "
-          f"cases per (dtype, MFMA-path d): {kinds}")
+          f"cases per (dtype, MFMA-path d): {kinds}; through the pair kernel: {pair_cases}")
     return 1 if fails else 0
 
 

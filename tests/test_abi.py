@@ -144,7 +144,16 @@ def test_plan_ex_describes_both_launches():
     # without the mask only short key sequences are "early"
     assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 4096, 4096, 128, False)] == [0, 16]
     assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 4096, 1000, 128, False)] == [16, 0]
-    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 64, True)] == [3, 0]
+    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 128, True)] == [3, 0]
+    # small causal problems at d = 64 (at most one 256-row unit per CU): the pair kernel -- 128-row blocks, 256 threads, two workgroups per CU
+    e3, m3 = fa.plan_ex(4, 8, 2048, 2048, 64, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, 0)
+    assert (e3["q_blocks"], m3["first_q_block"], m3["q_blocks"]) == (8, 8, 8)          # rows < 1024 = eight 128-row blocks take fp16 weights
+    assert e3["q_block_rows"] == m3["q_block_rows"] == 128 and e3["threads"] == m3["threads"] == 256 and e3["grid"] == m3["grid"] == 512
+    assert e3["lds_bytes"] == m3["lds_bytes"] <= 80 * 1024                              # two workgroups share a CU's 160 KiB
+    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 64, True)] == [5, 0]
+    # twice the heads: two 256-row units per CU, the persistent kernels again
+    assert fa.plan(8, 8, 2048, 64, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["threads"] == 512
+    assert fa.plan(4, 8, 2048, 64, False, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["threads"] == 512   # (BASELINE cfg1: no mask, nothing to pair)
     # padded head dimensions, fp32 and fp8 inputs have one form
     assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 80, True)] == [0, 3]
     assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 128, True, fa.FA_DTYPE_F32)][0] == 0
