@@ -183,7 +183,10 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
             plan->q_block_rows = 128;
             plan->threads = 256;
             plan->lds_bytes = bf16_causal_pair_lds_bytes(o_dtype);
-            plan->grid = 16 * (device_cus() / 8);
+            // grid: 8 XCD groups x (the largest group's units, or -- more units than CUs in a group -- two workgroups per CU)
+            const int jpx = device_cus() / 8;
+            const int64_t per_group = (((int64_t)B * H + 7) / 8) * getNumCta(S, 128);
+            plan->grid = 8 * (int)(per_group <= jpx ? per_group : 2 * jpx);
         }
     } else {
         plan->kernel_id = 0;
@@ -280,7 +283,7 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
             p.nQ = nQ_total;
             p.units = B * H * nQ_total;
             p.cpx = (p.units + 7) / 8;
-            p.jpx = plan.grid / 16;
+            p.jpx = device_cus() / 8;   // (workgroups of one dispatch round per XCD group: what the pairing counts in)
             e = launch_bf16_causal_pair(p, hp, p.jpx, plan, o_dtype, st);
         } else if (hp > 0 && hp < nQ_total && causal) {   // (without the mask early_q_blocks is all or nothing)
             if (two_lists_are_balanced(B * H, nQ_total, hp, S, Sk, plan.q_block_rows, device_cus() / 8)) {

@@ -28,7 +28,8 @@ hipError_t launch_pair(const Params& p, int hp, int jpx, const fa_launch_plan& p
 
 }  // namespace
 
-// p.nQ = 128-row query blocks per head; hp of them (the first ones) take fp16 weights; plan.grid = 16 jpx workgroups of 256 threads
+// p.nQ = 128-row query blocks per head; hp of them (the first ones) take fp16 weights; plan.grid = 8 x (a group's units, at most 2 jpx)
+// workgroups of 256 threads
 hipError_t launch_bf16_causal_pair(const Params& p, int hp, int jpx, const fa_launch_plan& plan, int o_dtype, hipStream_t st) {
     if (o_dtype == FA_DTYPE_F32) return launch_pair<float>(p, hp, jpx, plan, st);
     if (o_dtype == FA_DTYPE_BF16) return launch_pair<__bf16>(p, hp, jpx, plan, st);
