@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- forward attention TFLOP/s on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg2nc|cfg1|cfg3|cfg4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg2nc|cfg1|cfg1c|cfg3|cfg4]
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process (which has not touched the GPU) starts the N ranks
 itself -- a child `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same
@@ -52,6 +52,7 @@ WORKLOADS = {
     "cfg2": (8, 16, 4096, 128, True, "BASELINE cfg2: bf16 B=8 H=16 S=4096 d=128 causal"),
     "cfg2nc": (8, 16, 4096, 128, False, "BASELINE cfg2 shape, non-causal: bf16 B=8 H=16 S=4096 d=128"),
     "cfg1": (4, 8, 2048, 64, False, "BASELINE cfg1: bf16 B=4 H=8 S=2048 d=64 non-causal"),
+    "cfg1c": (4, 8, 2048, 64, True, "BASELINE cfg1's shape under the causal mask (not a BASELINE config): the pair kernel's case"),
     "cfg4": (64, 32, 8192, 128, False, "BASELINE cfg4: bf16 B=64 H=32 S=8192 d=128, B*H sharded over the ranks"),
     "cfg3": (1, 16, 16384, 128, False, "BASELINE cfg3: fp8 e4m3fn B=1 H=16 S=16384 d=128 non-causal (B, H chosen: unspecified)"),
 }
