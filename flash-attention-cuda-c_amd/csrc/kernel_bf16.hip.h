@@ -411,7 +411,8 @@ __global__ __launch_bounds__(64 * CA::NWAVES, 2) void fwd_mfma_dual_kernel(const
     run_units<CB, Kind::EARLY>(p, lb, (lds_ptr)smem_raw, hp);
 }
 
-// Small causal problems: ONE unit per workgroup, 128 query rows, four waves, two workgroups per CU.  With one 256-row unit per CU (or
+// Small causal problems: ONE unit per workgroup, 128 query rows, four waves; two workgroups per CU at d = 64, one at d = 128 (where the
+// launch simply reaches twice the CUs; jpx then covers every unit and nothing below is paired).  With one 256-row unit per CU (or
 // fewer) the launch lasts as long as its heaviest unit while the counted work is the mean -- 4.5 / 8 at BASELINE cfg1.  Here the units
 // are half as tall, every CU gets two of them, and the two are the heaviest and the lightest left of its XCD group's heads: workgroups
 // are dispatched in index order, one per CU and round, so x + 8 s (s < jpx) and x + 8 (jpx + s) share a CU; the first takes the

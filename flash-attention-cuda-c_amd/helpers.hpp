@@ -15,9 +15,9 @@
 //      a 3-slot ring = 96 KiB of the CU's 160 KiB LDS.
 //   Grid: persistent, one workgroup per CU walking ceil(units / CUs) units (kernel_bf16.hip.h: work_unit).
 //   Exception, decided per problem in csrc/FlashAttention.hip (pair_kernel_applies) because it depends on the shape, not on d and
-//      dtype alone: a causal bf16 problem at d = 64 with at most one 256-row unit per CU runs Br = 128 (4 waves), one unit per
-//      workgroup, two workgroups per CU paired heaviest + lightest (kernel_bf16.hip.h: fwd_mfma_pair_kernel); flash_attention_plan()
-//      reports that.
+//      dtype alone: a small causal bf16 problem (d = 64: at most one 256-row unit per CU; d = 128: per two CUs) runs Br = 128
+//      (4 waves), one unit per workgroup -- at d = 64 two workgroups per CU paired heaviest + lightest (kernel_bf16.hip.h:
+//      fwd_mfma_pair_kernel); flash_attention_plan() reports that.
 //   Head dimensions other than 64 / 128 (<= 128; multiples of 8 for bf16, 16 for fp8, 4 for fp32) run the next
 //      larger instantiation with their rows zero-padded on the fly.
 //   exact-fp32 MFMA kernel (fp32 inputs, d <= 128): Br = 128 (4 waves x 32 rows, 2 workgroups per CU),

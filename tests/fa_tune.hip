@@ -117,7 +117,7 @@ static std::vector<Variant> make_variants() {
                          launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>(a, grid);
                      }, 4});
     }
-    if constexpr (CAUSAL && D == 64) {
+    if constexpr (CAUSAL) {
         // small causal problems: 128-row units, one per workgroup, two workgroups per CU paired heavy + light (fwd_mfma_pair_kernel)
         auto pair = [](const Params& p, unsigned flags) {
             using CA = KernelCfg<D, true, float, 2, Opt{.m16 = 0, .waves = 4}>;
@@ -132,7 +132,8 @@ static std::vector<Variant> make_variants() {
             q.nQ = (p.S + 127) / 128;
             const int hp = flags == 2 ? 0 : std::min(q.nQ, 1024 / 128);
             const int jpx = g_cus / 8;
-            hipLaunchKernelGGL((fwd_mfma_pair_kernel<CA, CB>), dim3(8 * 2 * jpx), dim3(256), lds, nullptr, q, hp, jpx);
+            const int per_group = ((p.B * p.H + 7) / 8) * q.nQ;
+            hipLaunchKernelGGL((fwd_mfma_pair_kernel<CA, CB>), dim3(8 * (per_group <= jpx ? per_group : 2 * jpx)), dim3(256), lds, nullptr, q, hp, jpx);
         };
         v.push_back({"fp32 O, PAIR kernel: 128-row units, 2 workgroups per CU, default precision", [pair](const Params& p, int) { pair(p, 0); }, 4});
         v.push_back({"fp32 O, PAIR kernel: 128-row units, 2 workgroups per CU, bf16 weights", [pair](const Params& p, int) { pair(p, 2); }, 4});

@@ -144,8 +144,8 @@ def test_plan_ex_describes_both_launches():
     # without the mask only short key sequences are "early"
     assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 4096, 4096, 128, False)] == [0, 16]
     assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 4096, 1000, 128, False)] == [16, 0]
-    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 128, True)] == [3, 0]
-    # small causal problems at d = 64 (at most one 256-row unit per CU): the pair kernel -- 128-row blocks, 256 threads, two workgroups per CU
+    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 128, False)] == [3, 0]
+    # small causal problems: the pair kernel -- 128-row blocks, 256 threads.  d = 64: at most one 256-row unit per CU, two workgroups per CU
     e3, m3 = fa.plan_ex(4, 8, 2048, 2048, 64, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, 0)
     assert (e3["q_blocks"], m3["first_q_block"], m3["q_blocks"]) == (8, 8, 8)          # rows < 1024 = eight 128-row blocks take fp16 weights
     assert e3["q_block_rows"] == m3["q_block_rows"] == 128 and e3["threads"] == m3["threads"] == 256 and e3["grid"] == m3["grid"] == 512
@@ -154,6 +154,12 @@ def test_plan_ex_describes_both_launches():
     # twice the heads: two 256-row units per CU, the persistent kernels again
     assert fa.plan(8, 8, 2048, 64, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["threads"] == 512
     assert fa.plan(4, 8, 2048, 64, False, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["threads"] == 512   # (BASELINE cfg1: no mask, nothing to pair)
+    # d = 128: one workgroup per CU (a ring of 96 KiB), so at most one 256-row unit per two CUs -- the launch then covers twice the CUs
+    e4, m4 = fa.plan_ex(1, 8, 4096, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, 0)
+    assert (e4["q_blocks"], m4["q_blocks"], e4["q_block_rows"], e4["threads"], e4["grid"]) == (8, 24, 128, 256, 256)
+    assert 80 * 1024 < e4["lds_bytes"] == m4["lds_bytes"] <= 160 * 1024
+    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 128, True)] == [5, 0]
+    assert fa.plan(1, 16, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["threads"] == 512    # 256 units: one per CU, the persistent kernels
     # padded head dimensions, fp32 and fp8 inputs have one form
     assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 80, True)] == [0, 3]
     assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 128, True, fa.FA_DTYPE_F32)][0] == 0

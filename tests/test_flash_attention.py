@@ -767,22 +767,26 @@ def test_early_rows_meet_the_stated_tolerance_on_short_and_ragged_problems():
 
 
 PAIR_CASES = [
-    # (B, H, Sq, Sk, out dtype, weights): small causal problems at d = 64 -- at most one 256-row unit per CU -- take fwd_mfma_pair_kernel
-    (4, 8, 2048, 2048, torch.float32, None),             # BASELINE cfg1's shape under the mask: both precisions in the launch, 512 workgroups
-    (4, 8, 2048, 2048, torch.bfloat16, torch.bfloat16),  # bf16 weights on every row
-    (1, 3, 1000, 1000, torch.float32, None),             # ragged last block, 3 heads on 8 XCD groups, every row "early"
-    (3, 5, 1500, 1500, torch.float16, torch.float16),    # 15 heads: groups of 2 and 1 head(s), ragged, fp16 weights on every row
-    (2, 4, 700, 1900, torch.float32, None),              # more keys than queries: rows see up to 700 keys of 1900
-    (1, 16, 4000, 4000, torch.float32, None),            # 16 heads x 32 blocks = all 64 slots of every XCD group
+    # (B, H, Sq, Sk, d, out dtype, weights): small causal problems take fwd_mfma_pair_kernel -- d = 64: at most one 256-row unit per CU
+    (4, 8, 2048, 2048, 64, torch.float32, None),             # BASELINE cfg1's shape under the mask: both precisions in the launch, 512 workgroups
+    (4, 8, 2048, 2048, 64, torch.bfloat16, torch.bfloat16),  # bf16 weights on every row
+    (1, 3, 1000, 1000, 64, torch.float32, None),             # ragged last block, 3 heads on 8 XCD groups, every row "early"
+    (3, 5, 1500, 1500, 64, torch.float16, torch.float16),    # 15 heads: groups of 2 and 1 head(s), ragged, fp16 weights on every row
+    (2, 4, 700, 1900, 64, torch.float32, None),              # more keys than queries: rows see up to 700 keys of 1900
+    (1, 16, 4000, 4000, 64, torch.float32, None),            # 16 heads x 32 blocks = all 64 slots of every XCD group
+    # d = 128: one workgroup per CU, at most one 256-row unit per two CUs
+    (1, 8, 4096, 4096, 128, torch.float32, None),            # 128 units of 256 rows -> 256 of 128: every CU
+    (1, 8, 4096, 4096, 128, torch.bfloat16, torch.bfloat16),
+    (2, 3, 1100, 1100, 128, torch.float32, None),            # ragged, 6 heads on 8 XCD groups
+    (1, 5, 900, 3000, 128, torch.float16, torch.float16),    # more keys than queries, fp16 weights on every row
 ]
 
 
-@pytest.mark.parametrize("B,H,Sq,Sk,out_dtype,wd", PAIR_CASES)
-def test_pair_kernel_small_causal_d64(B, H, Sq, Sk, out_dtype, wd):
-    """The small-causal-problem kernel (128-row units, one per workgroup of four waves, two workgroups per CU paired heaviest +
-    lightest): O and LSE against the oracle, the plan says which kernel ran, and the result equals the persistent kernels' on the
-    same problem -- the same configurations compute the same rows -- to the last bit where the tile partition is the same."""
-    d = 64
+@pytest.mark.parametrize("B,H,Sq,Sk,d,out_dtype,wd", PAIR_CASES)
+def test_pair_kernel_small_causal(B, H, Sq, Sk, d, out_dtype, wd):
+    """The small-causal-problem kernel (128-row units, one per workgroup of four waves; d = 64: two workgroups per CU paired heaviest +
+    lightest, d = 128: one per CU): O and LSE against the oracle, the plan says which kernel ran, and the result equals the persistent
+    kernels' on the same heads -- the same configurations compute the same rows."""
     plan = fa.plan(B, H, Sq, d, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)
     assert plan["threads"] == 256 and plan["q_block_rows"] == 128
     Q, K, V = randn((B, H, Sq, d), 71, torch.bfloat16), randn((B, H, Sk, d), 72, torch.bfloat16), randn((B, H, Sk, d), 73, torch.bfloat16)
@@ -794,7 +798,7 @@ def test_pair_kernel_small_causal_d64(B, H, Sq, Sk, out_dtype, wd):
     check(O.float().cpu().numpy(), ref, atol, rtol)
     np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(Qf, Kf, causal=True), rtol=2e-6, atol=2e-3)
     if out_dtype == torch.float32 and wd is None:
-        rep = _parity_table(f"pair kernel B{B} H{H} Sq{Sq} Sk{Sk}", O.cpu().numpy(), ref)
+        rep = _parity_table(f"pair kernel B{B} H{H} Sq{Sq} Sk{Sk} d{d}", O.cpu().numpy(), ref)
         assert rep["pass_frac_at_1e-3"] == 1.0, rep           # the default precision's promise holds here too
     # the same heads inside a problem too large for the pair kernel (more heads): the persistent kernels compute them
     reps = 256 // (H * ((Sq + 255) // 256)) + 1
@@ -804,7 +808,7 @@ def test_pair_kernel_small_causal_d64(B, H, Sq, Sk, out_dtype, wd):
                             is_causal=True, out_dtype=out_dtype, weights_dtype=wd)
     torch.cuda.synchronize()
     diff = (Ob[:B].float() - O.float()).abs().max().item()
-    assert diff <= (1e-6 if out_dtype == torch.float32 else 8e-3), diff   # (same math, 128- against 256-row blocks: fp32 summation order of the masked tail)
+    assert diff <= (1e-6 if out_dtype == torch.float32 else 8e-3), diff   # (same math on 128- against 256-row blocks)
 
 
 def test_lse_request_changes_o_by_at_most_one_ulp():
