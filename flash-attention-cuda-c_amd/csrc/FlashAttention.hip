@@ -134,14 +134,15 @@ static bool two_lists_are_balanced(int64_t heads, int nQ_total, int hp, int S, i
     return ok;
 }
 
-// Small causal problems take the pair kernel (kernel_bf16.hip.h: fwd_mfma_pair_kernel): 128-row units, one per workgroup of four waves.
-// D = 64: two workgroups fit a CU -- at most one 256-row unit per CU (where the launch would last as long as its heaviest unit), and
-// every XCD group's 128-row units within its two dispatch rounds.  D = 128: one workgroup per CU -- at most one 256-row unit per TWO
-// CUs (half of the chip would idle), every group's 128-row units within one round.
+// Small problems take the pair kernel (kernel_bf16.hip.h: fwd_mfma_pair_kernel): 128-row units, one per workgroup of four waves.
+// Causal, D = 64: two workgroups fit a CU -- at most one 256-row unit per CU (where the launch would last as long as its heaviest
+// unit), and every XCD group's 128-row units within its two dispatch rounds.  Causal D = 128, and any D without the mask (equal units:
+// nothing to pair): one workgroup per CU -- at most one 256-row unit per TWO CUs (half of the chip would idle), every group's 128-row
+// units within one round.
 static bool pair_kernel_applies(int B, int H, int S, int d, bool causal, int dtype, float scale) {
-    if (!(dtype == FA_DTYPE_BF16 && (d == 64 || d == 128) && causal && scale > 0.f)) return false;
+    if (!(dtype == FA_DTYPE_BF16 && (d == 64 || d == 128) && scale > 0.f)) return false;
     const int64_t heads = (int64_t)B * H;
-    const int cus = device_cus(), jpx = cus / 8, rounds = d == 64 ? 2 : 1;
+    const int cus = device_cus(), jpx = cus / 8, rounds = (causal && d == 64) ? 2 : 1;
     if (heads * getNumCta(S, 256) * 2 > (int64_t)cus * rounds) return false;
     return ((heads + 7) / 8) * getNumCta(S, 128) <= rounds * jpx;
 }
@@ -184,7 +185,7 @@ static int make_plan(int B, int H, int S, int d, bool causal, int dtype, int o_d
             // 128-row units, one per workgroup of four waves, two workgroups per CU (grid = 16 per XCD-group workgroup slot pair)
             plan->q_block_rows = 128;
             plan->threads = 256;
-            plan->lds_bytes = d == 64 ? bf16_causal_pair_d64_lds_bytes(o_dtype) : bf16_causal_pair_d128_lds_bytes(o_dtype);
+            plan->lds_bytes = d == 64 ? bf16_pair_d64_lds_bytes(causal, o_dtype) : bf16_pair_d128_lds_bytes(causal, o_dtype);
             // grid: 8 XCD groups x (the largest group's units, or -- more units than CUs in a group -- two workgroups per CU)
             const int jpx = device_cus() / 8;
             const int64_t per_group = (((int64_t)B * H + 7) / 8) * getNumCta(S, 128);
@@ -286,7 +287,7 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
             p.units = B * H * nQ_total;
             p.cpx = (p.units + 7) / 8;
             p.jpx = device_cus() / 8;   // (workgroups of one dispatch round per XCD group: what the pairing counts in)
-            e = d == 64 ? launch_bf16_causal_pair_d64(p, hp, p.jpx, plan, o_dtype, st) : launch_bf16_causal_pair_d128(p, hp, p.jpx, plan, o_dtype, st);
+            e = d == 64 ? launch_bf16_pair_d64(p, hp, p.jpx, plan, causal, o_dtype, st) : launch_bf16_pair_d128(p, hp, p.jpx, plan, causal, o_dtype, st);
         } else if (hp > 0 && hp < nQ_total && causal) {   // (without the mask early_q_blocks is all or nothing)
             if (two_lists_are_balanced(B * H, nQ_total, hp, S, Sk, plan.q_block_rows, device_cus() / 8)) {
                 set_range(hp, nQ_total - hp, true);

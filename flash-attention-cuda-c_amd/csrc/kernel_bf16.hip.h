@@ -418,9 +418,11 @@ __global__ __launch_bounds__(64 * CA::NWAVES, 2) void fwd_mfma_dual_kernel(const
 // are dispatched in index order, one per CU and round, so x + 8 s (s < jpx) and x + 8 (jpx + s) share a CU; the first takes the
 // s-th heaviest unit of group x (causal: the highest query blocks of its heads), the second the s-th lightest.  Blocks below hp
 // (the rows that see fewer than FA_EARLY_KEYS keys) run configuration CB, the others CA (include/flash_attention.h, "Precision ...").
+// Without the mask the units are equal and the order means nothing: the kernel is then used only where 256-row units would leave half of
+// the CUs idle (one unit per workgroup, one dispatch round), and hp is all or nothing.
 template <class CA, class CB>
 __global__ __launch_bounds__(64 * CA::NWAVES, 2) void fwd_mfma_pair_kernel(const Params p, const int hp, const int jpx) {
-    static_assert(CA::NWAVES == 4 && CB::NWAVES == 4 && CA::CAUSAL && CB::CAUSAL, "the pairing is by causal weight");
+    static_assert(CA::NWAVES == 4 && CB::NWAVES == 4 && CA::CAUSAL == CB::CAUSAL, "one workgroup shape, one mask");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
     const int heads = p.B * p.H, hpx = (heads + 7) / 8;

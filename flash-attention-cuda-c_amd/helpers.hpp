@@ -15,7 +15,7 @@
 //      a 3-slot ring = 96 KiB of the CU's 160 KiB LDS.
 //   Grid: persistent, one workgroup per CU walking ceil(units / CUs) units (kernel_bf16.hip.h: work_unit).
 //   Exception, decided per problem in csrc/FlashAttention.hip (pair_kernel_applies) because it depends on the shape, not on d and
-//      dtype alone: a small causal bf16 problem (d = 64: at most one 256-row unit per CU; d = 128: per two CUs) runs Br = 128
+//      dtype alone: a small bf16 problem (causal at d = 64: at most one 256-row unit per CU; otherwise per two CUs) runs Br = 128
 //      (4 waves), one unit per workgroup -- at d = 64 two workgroups per CU paired heaviest + lightest (kernel_bf16.hip.h:
 //      fwd_mfma_pair_kernel); flash_attention_plan() reports that.
 //   Head dimensions other than 64 / 128 (<= 128; multiples of 8 for bf16, 16 for fp8, 4 for fp32) run the next

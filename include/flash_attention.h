@@ -220,7 +220,7 @@ int flash_attention_sharded(int nDevices, const int* deviceIds,
  */
 typedef struct fa_launch_plan {
     int q_block_rows;    /* Br: query rows per workgroup          (helpers.hpp:8-19); 256 on the MFMA paths' persistent kernels, 128 (and
-                            threads = 256) for small causal bf16 problems at dHead 64 / 128: the pair kernel */
+                            threads = 256) for small bf16 problems at dHead 64 / 128: the pair kernel */
     int kv_block_rows;   /* Bc: keys per inner-loop tile           (helpers.hpp:21-30) */
     int threads;         /* threads per workgroup                  (tests/main.cu:52)  */
     int grid;            /* number of workgroups                   (helpers.hpp:33-36) */

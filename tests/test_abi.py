@@ -135,16 +135,16 @@ def test_plan_ex_describes_both_launches():
     assert early["unit_lists"] == main["unit_lists"] == 2      # 12 late blocks per head x 16 heads per XCD group = 6 whole rounds of 32: balanced
     e2, m2 = fa.plan_ex(4, 16, 8192, 8192, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, 0)
     assert (e2["q_blocks"], m2["q_blocks"], e2["unit_lists"], m2["unit_lists"]) == (4, 28, 1, 1)      # 8 heads x 28 blocks = 7 rounds: the snake's pairs do not close
-    assert fa.plan_ex(1, 2, 4096, 4096, 128, False)[1]["unit_lists"] == 0
+    assert fa.plan_ex(8, 16, 4096, 4096, 128, False)[1]["unit_lists"] == 0
     assert early["lds_bytes"] == main["lds_bytes"] >= fa.plan(8, 16, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["lds_bytes"]
     early, main = fa.plan_ex(8, 16, 4096, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, fa.FA_FLAG_BF16_WEIGHTS)
     assert (early["q_blocks"], early["grid"], main["q_blocks"]) == (0, 0, 16)
     early, main = fa.plan_ex(8, 16, 4096, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, fa.FA_FLAG_F16_WEIGHTS)
     assert (early["q_blocks"], main["q_blocks"], main["grid"]) == (16, 0, 0)
     # without the mask only short key sequences are "early"
-    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 4096, 4096, 128, False)] == [0, 16]
-    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 4096, 1000, 128, False)] == [16, 0]
-    assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 128, False)] == [3, 0]
+    assert [x["q_blocks"] for x in fa.plan_ex(8, 16, 4096, 4096, 128, False)] == [0, 16]
+    assert [x["q_blocks"] for x in fa.plan_ex(8, 16, 4096, 1000, 128, False)] == [16, 0]
+    assert [x["q_blocks"] for x in fa.plan_ex(32, 16, 600, 600, 128, False)] == [3, 0]
     # small causal problems: the pair kernel -- 128-row blocks, 256 threads.  d = 64: at most one 256-row unit per CU, two workgroups per CU
     e3, m3 = fa.plan_ex(4, 8, 2048, 2048, 64, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, 0)
     assert (e3["q_blocks"], m3["first_q_block"], m3["q_blocks"]) == (8, 8, 8)          # rows < 1024 = eight 128-row blocks take fp16 weights
@@ -160,6 +160,11 @@ def test_plan_ex_describes_both_launches():
     assert 80 * 1024 < e4["lds_bytes"] == m4["lds_bytes"] <= 160 * 1024
     assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 128, True)] == [5, 0]
     assert fa.plan(1, 16, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["threads"] == 512    # 256 units: one per CU, the persistent kernels
+    # without the mask the units are equal: the same 128-row units only where 256-row units would leave half of the CUs idle
+    e5, m5 = fa.plan_ex(1, 8, 4096, 4096, 128, False, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, 0)
+    assert (e5["q_blocks"], m5["q_blocks"], m5["q_block_rows"], m5["threads"], m5["grid"]) == (0, 32, 128, 256, 256)
+    assert fa.plan(2, 8, 2048, 64, False, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["threads"] == 256      # 128 units of 256 rows
+    assert fa.plan(4, 8, 2048, 64, False, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["grid"] == 256          # BASELINE cfg1: 256 units, one per CU: unchanged
     # padded head dimensions, fp32 and fp8 inputs have one form
     assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 80, True)] == [0, 3]
     assert [x["q_blocks"] for x in fa.plan_ex(1, 2, 600, 600, 128, True, fa.FA_DTYPE_F32)][0] == 0

@@ -767,45 +767,54 @@ def test_early_rows_meet_the_stated_tolerance_on_short_and_ragged_problems():
 
 
 PAIR_CASES = [
-    # (B, H, Sq, Sk, d, out dtype, weights): small causal problems take fwd_mfma_pair_kernel -- d = 64: at most one 256-row unit per CU
-    (4, 8, 2048, 2048, 64, torch.float32, None),             # BASELINE cfg1's shape under the mask: both precisions in the launch, 512 workgroups
-    (4, 8, 2048, 2048, 64, torch.bfloat16, torch.bfloat16),  # bf16 weights on every row
-    (1, 3, 1000, 1000, 64, torch.float32, None),             # ragged last block, 3 heads on 8 XCD groups, every row "early"
-    (3, 5, 1500, 1500, 64, torch.float16, torch.float16),    # 15 heads: groups of 2 and 1 head(s), ragged, fp16 weights on every row
-    (2, 4, 700, 1900, 64, torch.float32, None),              # more keys than queries: rows see up to 700 keys of 1900
-    (1, 16, 4000, 4000, 64, torch.float32, None),            # 16 heads x 32 blocks = all 64 slots of every XCD group
-    # d = 128: one workgroup per CU, at most one 256-row unit per two CUs
-    (1, 8, 4096, 4096, 128, torch.float32, None),            # 128 units of 256 rows -> 256 of 128: every CU
-    (1, 8, 4096, 4096, 128, torch.bfloat16, torch.bfloat16),
-    (2, 3, 1100, 1100, 128, torch.float32, None),            # ragged, 6 heads on 8 XCD groups
-    (1, 5, 900, 3000, 128, torch.float16, torch.float16),    # more keys than queries, fp16 weights on every row
+    # (B, H, Sq, Sk, d, causal, out dtype, weights): small problems take fwd_mfma_pair_kernel -- causal d = 64: at most one 256-row unit per CU
+    (4, 8, 2048, 2048, 64, True, torch.float32, None),             # BASELINE cfg1's shape under the mask: both precisions in the launch, 512 workgroups
+    (4, 8, 2048, 2048, 64, True, torch.bfloat16, torch.bfloat16),  # bf16 weights on every row
+    (1, 3, 1000, 1000, 64, True, torch.float32, None),             # ragged last block, 3 heads on 8 XCD groups, every row "early"
+    (3, 5, 1500, 1500, 64, True, torch.float16, torch.float16),    # 15 heads: groups of 2 and 1 head(s), ragged, fp16 weights on every row
+    (2, 4, 700, 1900, 64, True, torch.float32, None),              # more keys than queries: rows see up to 700 keys of 1900
+    (1, 16, 4000, 4000, 64, True, torch.float32, None),            # 16 heads x 32 blocks = all 64 slots of every XCD group
+    # causal d = 128: one workgroup per CU, at most one 256-row unit per two CUs
+    (1, 8, 4096, 4096, 128, True, torch.float32, None),            # 128 units of 256 rows -> 256 of 128: every CU
+    (1, 8, 4096, 4096, 128, True, torch.bfloat16, torch.bfloat16),
+    (2, 3, 1100, 1100, 128, True, torch.float32, None),            # ragged, 6 heads on 8 XCD groups
+    (1, 5, 900, 3000, 128, True, torch.float16, torch.float16),    # more keys than queries, fp16 weights on every row
+    # without the mask (equal units): one workgroup per CU at either head dimension
+    (1, 8, 4096, 4096, 128, False, torch.float32, None),
+    (2, 8, 2048, 2048, 64, False, torch.float32, None),
+    (1, 3, 700, 700, 128, False, torch.float32, None),             # Sk < 1024: fp16 weights on every row
+    (3, 3, 1300, 2100, 64, False, torch.bfloat16, torch.bfloat16),
+    (1, 7, 1000, 5000, 128, False, torch.float16, torch.float16),
 ]
 
 
-@pytest.mark.parametrize("B,H,Sq,Sk,d,out_dtype,wd", PAIR_CASES)
-def test_pair_kernel_small_causal(B, H, Sq, Sk, d, out_dtype, wd):
-    """The small-causal-problem kernel (128-row units, one per workgroup of four waves; d = 64: two workgroups per CU paired heaviest +
-    lightest, d = 128: one per CU): O and LSE against the oracle, the plan says which kernel ran, and the result equals the persistent
-    kernels' on the same heads -- the same configurations compute the same rows."""
-    plan = fa.plan(B, H, Sq, d, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)
+@pytest.mark.parametrize("B,H,Sq,Sk,d,causal,out_dtype,wd", PAIR_CASES)
+def test_pair_kernel_small_problems(B, H, Sq, Sk, d, causal, out_dtype, wd):
+    """The small-problem kernel (128-row units, one per workgroup of four waves; causal d = 64: two workgroups per CU paired heaviest +
+    lightest, otherwise one per CU): O and LSE against the oracle, the plan says which kernel ran, and the result equals the persistent
+    kernels' on the same heads -- the same configurations compute the same rows (without the mask the persistent kernel that does not
+    return the LSE normalises by the MFMA sum of the ROUNDED weights, this one always by the fp32 sum: 2^-9 relative)."""
+    plan = fa.plan(B, H, Sq, d, causal, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)
     assert plan["threads"] == 256 and plan["q_block_rows"] == 128
     Q, K, V = randn((B, H, Sq, d), 71, torch.bfloat16), randn((B, H, Sk, d), 72, torch.bfloat16), randn((B, H, Sk, d), 73, torch.bfloat16)
     Qf, Kf, Vf = (t.float().numpy() for t in (Q, K, V))
-    ref = oracle.attention_numpy(Qf, Kf, Vf, causal=True)
-    O, lse = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=True, out_dtype=out_dtype, return_lse=True, weights_dtype=wd)
+    ref = oracle.attention_numpy(Qf, Kf, Vf, causal=causal)
+    O, lse = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, out_dtype=out_dtype, return_lse=True, weights_dtype=wd)
+    O1 = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, out_dtype=out_dtype, weights_dtype=wd)
     torch.cuda.synchronize()
+    assert torch.equal(O, O1)                                    # (one instantiation whether or not the LSE is asked for)
     atol, rtol = tol_for(torch.bfloat16, out_dtype)
     check(O.float().cpu().numpy(), ref, atol, rtol)
-    np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(Qf, Kf, causal=True), rtol=2e-6, atol=2e-3)
+    np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(Qf, Kf, causal=causal), rtol=2e-6, atol=2e-3)
     if out_dtype == torch.float32 and wd is None:
-        rep = _parity_table(f"pair kernel B{B} H{H} Sq{Sq} Sk{Sk} d{d}", O.cpu().numpy(), ref)
+        rep = _parity_table(f"pair kernel B{B} H{H} Sq{Sq} Sk{Sk} d{d} causal={causal}", O.cpu().numpy(), ref)
         assert rep["pass_frac_at_1e-3"] == 1.0, rep           # the default precision's promise holds here too
     # the same heads inside a problem too large for the pair kernel (more heads): the persistent kernels compute them
     reps = 256 // (H * ((Sq + 255) // 256)) + 1
-    big = fa.plan(B * reps, H, Sq, d, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)
+    big = fa.plan(B * reps, H, Sq, d, causal, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)
     assert big["threads"] == 512
-    Ob = fa.flash_attention(Q.repeat(reps, 1, 1, 1).to(DEV), K.repeat(reps, 1, 1, 1).to(DEV), V.repeat(reps, 1, 1, 1).to(DEV),
-                            is_causal=True, out_dtype=out_dtype, weights_dtype=wd)
+    Ob, _ = fa.flash_attention(Q.repeat(reps, 1, 1, 1).to(DEV), K.repeat(reps, 1, 1, 1).to(DEV), V.repeat(reps, 1, 1, 1).to(DEV),
+                               is_causal=causal, out_dtype=out_dtype, weights_dtype=wd, return_lse=True)
     torch.cuda.synchronize()
     diff = (Ob[:B].float() - O.float()).abs().max().item()
     assert diff <= (1e-6 if out_dtype == torch.float32 else 8e-3), diff   # (same math on 128- against 256-row blocks)
@@ -816,7 +825,8 @@ def test_lse_request_changes_o_by_at_most_one_ulp():
     fp32 (so the LSE is exact to fp32 rounding), a call that does not takes the row sums from the MFMA over the ROUNDED weights
     (include/flash_attention.h, flash_attention_lse).  The two normalisers differ by the rounding of the weights averaged over the
     row: O differs by at most one ulp of a bf16 output, and by <= 2^-9 relative in fp32."""
-    Q, K, V = (randn((2, 4, 2048, 128), s, torch.bfloat16) for s in (621, 622, 623))
+    Q, K, V = (randn((8, 8, 2048, 128), s, torch.bfloat16) for s in (621, 622, 623))   # (512 units: the persistent kernels)
+    assert fa.plan(8, 8, 2048, 128, False, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["threads"] == 512
     for causal in (False, True):
         o1 = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, out_dtype=torch.float32, weights_dtype=torch.bfloat16)
         o2, _ = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, out_dtype=torch.float32, weights_dtype=torch.bfloat16, return_lse=True)
