@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- forward attention TFLOP/s on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg2nc|cfg1|cfg1c|cfg3|cfg4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg2nc|cfg1|cfg1c|cfg3|cfg4|anchor]
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process (which has not touched the GPU) starts the N ranks
 itself -- a child `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same
@@ -45,7 +45,7 @@ sys.path.insert(0, os.path.join(ROOT, "profiles"))
 
 PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md)
 METRIC = "fwd attention TFLOP/s/GPU (bf16, seq=4096, d=128) + % MFMA peak"   # BASELINE.json, verbatim
-PROFILE_ROUND = "r03"       # profiles/<round>_hbm_traffic_<workload>.json is where roofline.traffic comes from
+PROFILE_ROUND = "r04"       # profiles/<round>_hbm_traffic_<workload>.json is where roofline.traffic comes from
 
 WORKLOADS = {
     # name: (B, H, S, d, causal, description)
@@ -55,7 +55,13 @@ WORKLOADS = {
     "cfg1c": (4, 8, 2048, 64, True, "BASELINE cfg1's shape under the causal mask (not a BASELINE config): the pair kernel's case"),
     "cfg4": (64, 32, 8192, 128, False, "BASELINE cfg4: bf16 B=64 H=32 S=8192 d=128, B*H sharded over the ranks"),
     "cfg3": (1, 16, 16384, 128, False, "BASELINE cfg3: fp8 e4m3fn B=1 H=16 S=16384 d=128 non-causal (B, H chosen: unspecified)"),
+    # not a BASELINE config: the shape class of the environment's best known-good structure (cdna_hip_programming.md, "4-wave,
+    # one-wave-per-SIMD, persistent structure": 1.25 PFLOP/s on random data with bf16 I/O at N = 2048, D = 128) -- bf16 in AND out
+    "anchor": (16, 16, 2048, 128, False, "anchor (not a BASELINE config): bf16 in/out B=16 H=16 S=2048 d=128 non-causal, the guide's 1.25 PFLOP/s shape class"),
 }
+# element type of O when --out-dtype is not given: fp32 (the reference's float* O) except for the anchor, whose yardstick is bf16 I/O
+DEFAULT_OUT_DTYPE = {"anchor": "bf16"}
+ANCHOR_GUIDE_TFLOPS = 1250.0   # cdna_hip_programming.md, Appendix B "Fused attention prefill": the hand-placed 4-wave kernel, random data
 # parity.pass_frac_at_1e-3 below this fails the run: every sampled element with fp32 output (the stated tolerance, met by the
 # default weight precisions: include/flash_attention.h); 2-byte outputs add their own rounding (2^-9 relative for bf16)
 PARITY_FLOOR = {"f32": 1.0, "bf16": 0.998}
@@ -93,6 +99,33 @@ def bound_for(workload):
           "ceiling_tflops": round(PEAK_BF16_TFLOPS * useful / max(pipe, issue), 1),
           "binds": "vector issue" if issue > pipe else "mfma pipe"}
     return "mfma", PEAK_BF16_TFLOPS, "nominal dense bf16 MFMA peak: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz", ib
+
+
+def launched_kernel(fa, B, H, S, d, causal, dtype_code, o_code, flags):
+    """Name of the kernel the library launches for this problem, from the plan the library itself reports
+    (flash_attention_plan_ex): 256 threads = the pair kernel; both ranges in one launch (unit_lists 1 or 2) = the dual kernel;
+    else the single persistent kernel.  (profiles/*_kernel_stats_*.csv carry the same names from rocprofv3.)"""
+    early, main = fa.plan_ex(B, H, S, S, d, causal, dtype_code, o_code, flags)
+    live = main if main["q_blocks"] > 0 else early
+    if live["kernel_id"] == 3:
+        return "fa::fwd_f32_mfma_kernel"
+    if live["kernel_id"] == 0:
+        return "fa::fwd_generic_kernel"
+    if live["threads"] == 256:
+        return "fa::fwd_mfma_pair_kernel"
+    if early["q_blocks"] > 0 and main["q_blocks"] > 0 and live["unit_lists"] in (1, 2):
+        return "fa::fwd_mfma_dual_kernel"
+    return "fa::fwd_mfma_kernel"
+
+
+def visible_devices():
+    """GPUs this process may use.  torch.cuda.device_count() does not initialise the GPU on this image; the test suite injects a
+    count through FA_BENCH_VISIBLE_DEVICES (CPU box: tests/test_bench_contract.py)."""
+    fake = os.environ.get("FA_BENCH_VISIBLE_DEVICES")
+    if fake is not None:
+        return int(fake)
+    import torch
+    return int(torch.cuda.device_count())
 
 
 def measured_traffic(workload):
@@ -133,7 +166,7 @@ def power_limited_ceiling():
         return None
 
 
-def cpu_baseline_and_parity(Q, K, V, O, S, d, causal, budget_s=12.0):
+def cpu_baseline_and_parity(Q, K, V, O, S, d, causal, budget_s=12.0, heads_at=None):
     """Naive fp32 attention (the oracle, a port of tests/main.cu:74-91 / check.py:19-21) on the host cores, on a bounded
     sample of THIS run's tensors: as many whole heads of the workload as fit ~budget_s.  The same result is the checker
     for the GPU output of those heads (`parity`).  Q, K, V, O: the rank's [heads, 1, S, d] device tensors."""
@@ -153,6 +186,17 @@ def cpu_baseline_and_parity(Q, K, V, O, S, d, causal, budget_s=12.0):
 
     heads = Q.shape[0]
     timed(0, 1)                      # warm-up: thread pool start, first touch
+    if heads_at is not None:         # parity only, on the given whole heads (cfg4: either side of the 2^31-byte line, first and last)
+        from parity import parity_report as _pr
+        gots, refs, t_all, thr = [], [], 0.0, 1
+        for h in heads_at:
+            t, thr, ref = timed(h, 1)
+            t_all += t
+            refs.append(ref)
+            gots.append(O[h:h + 1].float().cpu().numpy().reshape(1, 1, S, d))
+        par = _pr(np.concatenate(gots, 1), np.concatenate(refs, 1))
+        par["checked"] = f"GPU output of whole heads {list(heads_at)} of this rank's slab (every row) against the oracle's result on the same (rounded) inputs; {t_all:.2f} s on {int(thr)} host cores"
+        return None, par
     t1, thr, _ = timed(0, 1)
     nh = int(max(1, min(heads, budget_s / max(t1, 1e-3))))
     h0 = heads - nh                  # the LAST heads of the slab (the first are the easy ones to get right)
@@ -166,7 +210,7 @@ def cpu_baseline_and_parity(Q, K, V, O, S, d, causal, budget_s=12.0):
     return base, par
 
 
-def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps, warmup, dry, want_parity, out_dtype, prime=True):
+def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps, warmup, dry, want_parity, out_dtype, prime=True, parity_heads=None):
     """One workload on this rank; returns the rank-0 record (None elsewhere)."""
     B, H, S, d, causal, desc = WORKLOADS[workload]
     if workload == "cfg4":           # fixed total problem, B*H split over the ranks (strong scaling)
@@ -259,8 +303,12 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
     achieved = flops_of(heads_local, S, d, causal) / (kernel_ms_max * 1e-3) / 1e12
     bound, peak, why, issue_bound = bound_for(workload)
     # (the committed PMC run is of the default call: fp32 output, default weight precision)
-    traffic, prov = measured_traffic(workload) if world == 1 and out_dtype == args.out_dtype == "f32" and args.weights == "default" else (None, None)
+    default_call = out_dtype == DEFAULT_OUT_DTYPE.get(workload, "f32") and args.weights == "default"
+    traffic, prov = measured_traffic(workload) if world == 1 and default_call else (None, None)
     algo_bytes = heads_local * S * d * (3 * esz + osz)
+    flags = {"default": 0, "bf16": fa.FA_FLAG_BF16_WEIGHTS, "f16": fa.FA_FLAG_F16_WEIGHTS}[args.weights] if esz == 2 else 0
+    kernel = launched_kernel(fa, heads_local, 1, S, d, causal, fa.FA_DTYPE_FP8_E4M3 if esz == 1 else fa.FA_DTYPE_BF16,
+                             fa.FA_DTYPE_BF16 if out_dtype == "bf16" else fa.FA_DTYPE_F32, flags)
     rec = {
         "metric": METRIC if workload.startswith("cfg2") else f"fwd attention TFLOP/s/GPU ({desc}) + % MFMA peak",
         "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": steps,
@@ -290,14 +338,23 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "peak_derivation": why,
                      "issue_bound": issue_bound,
                      "traffic": traffic, "traffic_provenance": prov,
-                     "kernel": "fa::fwd_mfma_kernel", "kernel_ms": round(kernel_ms_max, 5),
+                     # HBM bytes the counters saw per algorithmic byte (1.0 = every byte moved once; > 1 = re-reads beyond the XCD's L2)
+                     "traffic_ratio": round(traffic / algo_bytes, 3) if traffic else None,
+                     # from the library's own plan for this call (flash_attention_plan_ex), not a literal
+                     "kernel": kernel, "kernel_ms": round(kernel_ms_max, 5),
                      "algorithmic_hbm_bytes": algo_bytes,
                      "algorithmic_hbm_GBps": round(algo_bytes / (kernel_ms_max * 1e-3) / 1e9, 1)},
     }
     if dry:
         rec["dry_run"] = True
-    if want_parity and not dry:
-        rec["cpu_baseline"], rec["parity"] = cpu_baseline_and_parity(Q, K, V, O, S, d, causal, budget_s=args.cpu_budget_s)
+    if workload == "anchor":
+        rec["anchor"] = {"guide_best_known_tflops": ANCHOR_GUIDE_TFLOPS, "ratio_to_guide": round(value / world / ANCHOR_GUIDE_TFLOPS, 4),
+                         "source": "cdna_hip_programming.md Appendix B: 4-wave one-wave-per-SIMD persistent kernel, bf16 I/O, N=2048 D=128, random data"}
+    if (want_parity or parity_heads) and not dry:
+        hs = [h for h in (parity_heads or []) if 0 <= h < heads_local] or None
+        base, rec["parity"] = cpu_baseline_and_parity(Q, K, V, O, S, d, causal, budget_s=args.cpu_budget_s, heads_at=hs)
+        if base is not None:
+            rec["cpu_baseline"] = base
         floor = PARITY_FLOOR[out_dtype]
         rec["parity"]["floor"] = floor
         if rec["parity"]["pass_frac_at_1e-3"] < floor:
@@ -330,8 +387,8 @@ def main():
     ap.add_argument("--no-ceiling", action="store_true", help="skip the power-limited-ceiling microbenchmark")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the cfg4 strong-scaling sub-record")
     ap.add_argument("--no-bf16-out", action="store_true", help="skip the bf16-output sub-record")
-    ap.add_argument("--out-dtype", default="f32", choices=["bf16", "f32"],
-                    help="element type of O; f32 = the reference's float* O (kernels/FlashAttention.cuh:61)")
+    ap.add_argument("--out-dtype", default=None, choices=["bf16", "f32"],
+                    help="element type of O; default f32 = the reference's float* O (kernels/FlashAttention.cuh:61); the anchor workload: bf16")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="seconds of host-core time for the CPU baseline / parity sample (whole heads)")
     ap.add_argument("--weights", default="default", choices=["default", "bf16", "f16"],
                     help="softmax-weight precision (bf16 inputs): the library default, or one precision on every row (FA_FLAG_*_WEIGHTS)")
@@ -339,6 +396,17 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.out_dtype is None:
+        args.out_dtype = DEFAULT_OUT_DTYPE.get(args.workload, "f32")
+
+    # More ranks than visible GPUs: say so in one line and leave with a status of its own, BEFORE any rendezvous (the parent checks
+    # before it starts the ranks, a rank started by someone else's torchrun before init_process_group).  Not for --dry-run (CPU, gloo)
+    # unless a count is injected (FA_BENCH_VISIBLE_DEVICES: the test suite).
+    if not args.dry_run or "FA_BENCH_VISIBLE_DEVICES" in os.environ:
+        n_vis = visible_devices()
+        if n_vis < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {n_vis} GPU(s) visible to this process: nothing started", file=sys.stderr, flush=True)
+            return 4
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, sys.argv[1:])
@@ -393,11 +461,19 @@ def main():
             line["bf16_out"]["roofline"] = {k: sub["roofline"][k] for k in ("achieved", "peak", "frac", "kernel_ms")}
     # BASELINE configs[4] itself, its 2048 heads split over the ranks (the driver never passes --workload cfg4); N = 1: the anchor
     if not args.no_cfg4 and args.workload != "cfg4":
-        sub = run_workload(fa, shard, torch, dist, args, "cfg4", world, rank, dev, few, 1, args.dry_run, False, args.out_dtype, prime=False)
+        # parity of cfg4 at the stated tolerance on whole heads of rank 0's slab: the first, the two either side of the 2^31-byte
+        # line of the whole problem (heads 1023 | 1024; on a shard: its middle), and the last
+        n_loc = shard.shard_heads(64 * 32, rank, world)
+        n_loc = n_loc[1] - n_loc[0]
+        c4_heads = sorted({0, n_loc // 2 - 1, n_loc // 2, n_loc - 1}) if (world == 1 and not args.no_cpu_baseline) else None
+        sub = run_workload(fa, shard, torch, dist, args, "cfg4", world, rank, dev, few, 1, args.dry_run, False, args.out_dtype, prime=False,
+                           parity_heads=c4_heads)
         if rank == 0:
             line["cfg4"] = {k: sub[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_median", "ms_min", "scaling", "config",
                                                  "value_per_gpu", "pct_of_bf16_mfma_peak", "output_ok")}
-            line["cfg4"]["roofline"] = {k: sub["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms")}
+            line["cfg4"]["roofline"] = {k: sub["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms")}
+            if "parity" in sub:
+                line["cfg4"]["parity"] = sub["parity"]
     rc = 0
     if rank == 0:
         if not line["output_ok"]:

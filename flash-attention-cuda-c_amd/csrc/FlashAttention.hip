@@ -124,13 +124,24 @@ static double snake_imbalance(int64_t heads, int nq, int qb0, int S, int Sk, int
 // Causal default precision: walk two lists of their own (late blocks, early blocks) or the single kernel's list twice?  Two lists are
 // the faster form where the late list's schedule is balanced (fwd_mfma_dual_kernel).
 static bool two_lists_are_balanced(int64_t heads, int nQ_total, int hp, int S, int Sk, int qrows, int jpx_max) {
-    // (the walk is up to 64 Ki steps: a caller that repeats a shape -- every caller in practice -- pays for it once per thread)
-    struct Memo { int64_t heads; int nQ, hp, S, Sk, qrows, jpx; bool ok; bool valid; };
-    static thread_local Memo m{};
-    if (m.valid && m.heads == heads && m.nQ == nQ_total && m.hp == hp && m.S == S && m.Sk == Sk && m.qrows == qrows && m.jpx == jpx_max)
-        return m.ok;
+    // (the walk is up to 64 Ki steps: a caller pays for it once per shape and thread -- a small per-thread LRU, so that a caller
+    //  that alternates a few causal shapes, prefill chunks of several lengths say, does not walk on every launch)
+    struct Memo { int64_t heads; int nQ, hp, S, Sk, qrows, jpx; bool ok; uint64_t used; };
+    constexpr int WAYS = 16;
+    static thread_local Memo memo[WAYS] = {};
+    static thread_local uint64_t tick = 0;
+    ++tick;
+    int victim = 0;
+    for (int i = 0; i < WAYS; ++i) {
+        Memo& m = memo[i];
+        if (m.used && m.heads == heads && m.nQ == nQ_total && m.hp == hp && m.S == S && m.Sk == Sk && m.qrows == qrows && m.jpx == jpx_max) {
+            m.used = tick;
+            return m.ok;
+        }
+        if (m.used < memo[victim].used) victim = i;   // (an empty way has used == 0: taken first)
+    }
     const bool ok = snake_imbalance(heads, nQ_total - hp, hp, S, Sk, qrows, jpx_max) <= 1.02;
-    m = Memo{heads, nQ_total, hp, S, Sk, qrows, jpx_max, ok, true};
+    memo[victim] = Memo{heads, nQ_total, hp, S, Sk, qrows, jpx_max, ok, tick};
     return ok;
 }
 

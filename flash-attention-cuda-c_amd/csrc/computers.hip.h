@@ -308,7 +308,7 @@ struct WaveCompute {
 
     // ---- the slots -----------------------------------------------------------------------------
     // phase A slot I: fragment f = I/(MPF*R), then (sub, row group) = ((I % (MPF*R)) / R, I % R)
-    template <int I>
+    template <int I, bool DMA_A = true>
     __device__ __forceinline__ void slots_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase,
                                             float c, const Scores<R>& cur, Scores<R>& nxt) {
         if constexpr (I < SA) {
@@ -328,15 +328,15 @@ struct WaveCompute {
                 constexpr int v = I - (SA - VPRE);
                 vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DB, v % DB);
             }
-            load_in_slot<I>(st, t_load);
+            if constexpr (DMA_A) load_in_slot<I>(st, t_load);
             if constexpr (!C::VALU_FIRST) exp_slot<I>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
-            slots_a<I + 1>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+            slots_a<I + 1, DMA_A>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         }
     }
     // phase B slot J: V^T fragment v = J/R (16-key step v/DB, d block v%DB), row group J%R
-    template <bool TRACK, int J>
-    __device__ __forceinline__ void slots_b(Stage& st, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
+    template <bool TRACK, int J, bool DMA_B = false>
+    __device__ __forceinline__ void slots_b(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
                                             const Scores<R>& cur, const Scores<R>& nxt) {
         if constexpr (J < SB) {
             constexpr int v = J / R, rg = J % R, s4 = v / DB, db = v % DB;
@@ -345,13 +345,14 @@ struct WaveCompute {
                 constexpr int vn = v + VPRE;
                 vf[vn % (VPRE + 1)] = v_frag(v_cur, vbase, vn / DB, vn % DB);
             }
+            if constexpr (DMA_B) load_in_slot<J>(st, t_load);
             exp_slot<SA + J>(cur, c);
             if constexpr (TRACK && J < SB / 2) max3_slot<J>(nxt);
             if constexpr (TRACK && J == SB / 2) decide(c);
             if constexpr (J >= SB / 2 && (J - SB / 2) % WSTEP == 0 && (J - SB / 2) / WSTEP < NW)
                 st.template write<(J - SB / 2) / WSTEP>(wr_slot);
             __builtin_amdgcn_sched_barrier(0);
-            slots_b<TRACK, J + 1>(st, wr_slot, v_cur, vbase, c, cur, nxt);
+            slots_b<TRACK, J + 1, DMA_B>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt);
         }
     }
 
@@ -359,11 +360,12 @@ struct WaveCompute {
     // does not need and ignored: one hot code path).
     // TRACK = true: running row max with lazy rescale (always safe).  TRACK = false: the optimistic
     // pass -- m stays the row max of tile 0 and no max / decision / rescale is issued.
-    template <bool TRACK>
-    __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
-                                              int kbase, int vbase, float c, const Scores<R>& cur, Scores<R>& nxt,
-                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
-        st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
+    // The step comes in two halves so that the staggered kernels (KernelCfg::STAG) can put the workgroup barrier between them
+    // for half of the waves: tile_a = phase A, tile_b = phase B + the end-of-tile work.  DMA_A / DMA_B: which half issues the
+    // wave's LDS-DMA pieces of tile t_load (the caller has set their destination: Stage::set_dst / set_dst2).
+    template <bool DMA_A = true>
+    __device__ __forceinline__ void tile_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase, float c,
+                                           const Scores<R>& cur, Scores<R>& nxt) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             sum_a[r] = sum_b[r] = 0.f;
@@ -374,13 +376,18 @@ struct WaveCompute {
         for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
         if constexpr (C::PRIO_A) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
-        slots_a<0>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        slots_a<0, DMA_A>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         if constexpr (C::PRIO_A) {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (C::STAMP) t_mid = cycle_stamp();
-        slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
+    }
+    template <bool TRACK, bool DMA_B = false>
+    __device__ __forceinline__ void tile_b(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
+                                           const Scores<R>& cur, Scores<R>& nxt,
+                                           bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
+        slots_b<TRACK, 0, DMA_B>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
 #pragma unroll
         for (int r = 0; r < R; ++r) l[r] += sum_a[r] + sum_b[r];
@@ -410,6 +417,14 @@ struct WaveCompute {
                 }
             }
         }
+    }
+    template <bool TRACK>
+    __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
+                                              int kbase, int vbase, float c, const Scores<R>& cur, Scores<R>& nxt,
+                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
+        st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
+        tile_a<true>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        tile_b<TRACK, false>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt, has_next, mask_next, kv0_next, q_row0, S, lane);
     }
 
     // True iff a row sum or any O accumulator of this lane is inf / NaN (x*0 is NaN for both).  Four independent

@@ -61,8 +61,12 @@ struct WaveCompute16 {
     static constexpr int SPAN = SA + SB / 2;       // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
     using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, true, false>, BufStage<D, ESZ, C::NWAVES, C::PAD, true, C::P_F16>>;
-    // the P.V operand type: bf16, or fp16 with the fp16-weights option (weights rounded to 11 bits instead of 8; V staged as fp16)
-    using pv_t = std::conditional_t<C::P_F16, f16x8, bf16x8>;
+    // the P.V operand type: bf16, or fp16 with the fp16-weights option (weights rounded to 11 bits instead of 8; V staged as fp16).
+    // F16W is a property of the PASS, not of the kernel: the fp16-weights kernels fall back to a bf16-weights tracked pass when
+    // fp16 cannot hold the unit's V (|v| > 65504 becomes inf: kernel_bf16.hip.h, run_units), so every member that touches the
+    // weights' or V's type takes it as a template argument that defaults to the kernel's C::P_F16
+    template <bool F16W> using pv_of = std::conditional_t<F16W, f16x8, bf16x8>;
+    using pv_t = pv_of<C::P_F16>;
     using ScoresT = Scores16;
     static constexpr int NL = Stage::NL, NW = Stage::NW;
     static constexpr int WSTEP = 2 * NW <= SB / 2 + 1 ? 2 : 1;   // LDS writes sit in every WSTEP-th slot of the second half of phase B
@@ -110,12 +114,14 @@ struct WaveCompute16 {
         if constexpr (C::SUM_MFMA) return lsum[qg][0];
         else return sum_all_quarters(l[qg]);
     }
-    __device__ __forceinline__ static pv_t ones_frag() {
-        constexpr uint32_t one2 = C::P_F16 ? 0x3c003c00u : 0x3f803f80u;
+    template <bool F16W = C::P_F16>
+    __device__ __forceinline__ static pv_of<F16W> ones_frag() {
+        constexpr uint32_t one2 = F16W ? 0x3c003c00u : 0x3f803f80u;
         u32x4 v = {one2, one2, one2, one2};
-        return __builtin_bit_cast(pv_t, v);
+        return __builtin_bit_cast(pv_of<F16W>, v);
     }
-    __device__ __forceinline__ static uint32_t pack_p(float lo, float hi) { return C::P_F16 ? pack_f16(lo, hi) : pack_bf16(lo, hi); }
+    template <bool F16W = C::P_F16>
+    __device__ __forceinline__ static uint32_t pack_p(float lo, float hi) { return F16W ? pack_f16(lo, hi) : pack_bf16(lo, hi); }
 
     // Q fragment (qg, ks) of row q = row0 + 16*qg + (lane&15): 16 bytes at byte 64*ks + 16*h4 of the row.
     __device__ __forceinline__ void load_q(const char* Qh, int64_t qS_bytes, int row0, int S, int lane, int row_bytes = D * ESZ) {
@@ -226,7 +232,7 @@ struct WaveCompute16 {
     }
 
     // ---- softmax slices ------------------------------------------------------------------------
-    template <int E>
+    template <int E, bool F16W = C::P_F16>
     __device__ __forceinline__ void exp_elem(const Scores16& cur, float c) {
         constexpr int kk = E / 16, qg = (E / 8) % 2, j = E % 8, kg = 2 * kk + (j >> 2), reg = j & 3;
         const float p = fast_exp2(fmaf(cur.s[kg][qg][reg], c, -m[qg]));
@@ -237,22 +243,23 @@ struct WaveCompute16 {
         // (empty asm: pins the value in this slot -- hipcc otherwise sinks the arithmetic towards its first use, behind the MFMAs
         //  or, when the slot sequence holds a branch, into the block behind it)
         if constexpr (j & 1) {
-            pw[qg][kk][j >> 1] = pack_p(p_even, p);
+            pw[qg][kk][j >> 1] = pack_p<F16W>(p_even, p);
             if constexpr (!C::SUM_MFMA) asm volatile("" : "+v"(sum_a[qg]), "+v"(sum_b[qg]));
         } else {
             p_even = p;
         }
     }
-    template <int SLOT, int E = 0>
+    template <int SLOT, bool F16W = C::P_F16, int E = 0>
     __device__ __forceinline__ void exp_slot(const Scores16& cur, float c) {
         if constexpr (E < NE) {
-            if constexpr (elem_slot(E) == SLOT) exp_elem<E>(cur, c);
-            exp_slot<SLOT, E + 1>(cur, c);
+            if constexpr (elem_slot(E) == SLOT) exp_elem<E, F16W>(cur, c);
+            exp_slot<SLOT, F16W, E + 1>(cur, c);
         }
     }
-    __device__ __forceinline__ pv_t p_frag(int qg, int kk) const {
+    template <bool F16W = C::P_F16>
+    __device__ __forceinline__ pv_of<F16W> p_frag(int qg, int kk) const {
         u32x4 v = {pw[qg][kk][0], pw[qg][kk][1], pw[qg][kk][2], pw[qg][kk][3]};
-        return __builtin_bit_cast(pv_t, v);
+        return __builtin_bit_cast(pv_of<F16W>, v);
     }
     // tracked pass: v_max3 chains over 64/SB values of S(t+1) in slot J (J < SB/2); 32 values in all
     template <int J>
@@ -289,69 +296,73 @@ struct WaveCompute16 {
 
     // ---- the slots -----------------------------------------------------------------------------
     // phase A slot I: K fragment f = I / QG, query group I % QG
-    template <int I>
+    template <int I, bool DMA_A = true, bool F16W = C::P_F16>
     __device__ __forceinline__ void slots_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase,
                                             float c, const Scores16& cur, Scores16& nxt) {
         if constexpr (I < SA) {
             constexpr int f = I / QG, qg = I % QG;
-            if constexpr (C::VALU_FIRST) exp_slot<I>(cur, c);
+            if constexpr (C::VALU_FIRST) exp_slot<I, F16W>(cur, c);
             qk_mfma<f, qg>(kf[f % NPRE], nxt);
             if constexpr (qg == QG - 1 && f + NPRE < NF) kf[f % NPRE] = k_read(k_next, kbase, f + NPRE);
             if constexpr (I >= SA - VPRE) {   // the last VPRE phase-A slots start the V^T window of phase B
                 constexpr int v = I - (SA - VPRE);
                 vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DG, v % DG);
             }
-            load_in_slot<I>(st, t_load);
-            if constexpr (!C::VALU_FIRST) exp_slot<I>(cur, c);
+            if constexpr (DMA_A) load_in_slot<I>(st, t_load);
+            if constexpr (!C::VALU_FIRST) exp_slot<I, F16W>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
-            slots_a<I + 1>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+            slots_a<I + 1, DMA_A, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         }
     }
     // phase B slot J: V^T fragment v = J / QG (k-step v / DG, d group v % DG), query group J % QG
-    template <bool TRACK, int J>
-    __device__ __forceinline__ void slots_b(Stage& st, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
+    template <bool TRACK, int J, bool DMA_B = false, bool F16W = C::P_F16>
+    __device__ __forceinline__ void slots_b(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
                                             const Scores16& cur, const Scores16& nxt) {
         if constexpr (J < SB) {
             constexpr int v = J / QG, qg = J % QG, kk = v / DG, dg = v % DG;
-            o[qg][dg] = mfma_16x16x32(__builtin_bit_cast(pv_t, vf[v % (VPRE + 1)]), p_frag(qg, kk), o[qg][dg]);
-            if constexpr (C::SUM_MFMA && dg == 1) lsum[qg] = mfma_16x16x32(ones_frag(), p_frag(qg, kk), lsum[qg]);   // row sums of this k-step
+            o[qg][dg] = mfma_16x16x32(__builtin_bit_cast(pv_of<F16W>, vf[v % (VPRE + 1)]), p_frag<F16W>(qg, kk), o[qg][dg]);
+            if constexpr (C::SUM_MFMA && dg == 1) lsum[qg] = mfma_16x16x32(ones_frag<F16W>(), p_frag<F16W>(qg, kk), lsum[qg]);   // row sums of this k-step
             if constexpr (qg == QG - 1 && v + VPRE < NV) {
                 constexpr int vn = v + VPRE;
                 vf[vn % (VPRE + 1)] = v_frag(v_cur, vbase, vn / DG, vn % DG);
             }
-            exp_slot<SA + J>(cur, c);
+            if constexpr (DMA_B) load_in_slot<J>(st, t_load);
+            exp_slot<SA + J, F16W>(cur, c);
             if constexpr (TRACK && J < SB / 2) max3_slot<J>(nxt);
             if constexpr (TRACK && J == SB / 2) decide(c);
             if constexpr (J >= SB / 2 && (J - SB / 2) % WSTEP == 0 && (J - SB / 2) / WSTEP < NW)
-                st.template write<(J - SB / 2) / WSTEP>(wr_slot);
+                st.template write<(J - SB / 2) / WSTEP, F16W>(wr_slot);
             __builtin_amdgcn_sched_barrier(0);
-            slots_b<TRACK, J + 1>(st, wr_slot, v_cur, vbase, c, cur, nxt);
+            slots_b<TRACK, J + 1, DMA_B, F16W>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt);
         }
     }
 
-    // One tile: cur = S(t) (consumed), nxt = S(t+1) (produced).  Same contract as WaveCompute::tile_step.
-    template <bool TRACK>
-    __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
-                                              int kbase, int vbase, float c, const Scores16& cur, Scores16& nxt,
-                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
+    // One tile: cur = S(t) (consumed), nxt = S(t+1) (produced).  Same contract as WaveCompute::tile_step / tile_a / tile_b.
+    template <bool DMA_A = true, bool F16W = C::P_F16>
+    __device__ __forceinline__ void tile_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase, float c,
+                                           const Scores16& cur, Scores16& nxt) {
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
             mx_a[qg] = mx_b[qg] = -INFINITY;
             sum_a[qg] = sum_b[qg] = 0.f;
         }
         zero(nxt);
-        st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
         if constexpr (C::PRIO_A) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
-        slots_a<0>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        slots_a<0, DMA_A, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         if constexpr (C::PRIO_A) {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (C::STAMP) t_mid = cycle_stamp();
-        slots_b<TRACK, 0>(st, wr_slot, v_cur, vbase, c, cur, nxt);
+    }
+    template <bool TRACK, bool DMA_B = false, bool F16W = C::P_F16>
+    __device__ __forceinline__ void tile_b(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
+                                           const Scores16& cur, Scores16& nxt,
+                                           bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
+        slots_b<TRACK, 0, DMA_B, F16W>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
         if constexpr (!C::SUM_MFMA) {
 #pragma unroll
@@ -380,6 +391,14 @@ struct WaveCompute16 {
                 }
             }
         }
+    }
+    template <bool TRACK, bool F16W = C::P_F16>
+    __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
+                                              int kbase, int vbase, float c, const Scores16& cur, Scores16& nxt,
+                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
+        st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
+        tile_a<true, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        tile_b<TRACK, false, F16W>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt, has_next, mask_next, kv0_next, q_row0, S, lane);
     }
 
     // True iff a row sum or any O accumulator of this lane is inf / NaN (x*0 is NaN for both); four independent chains.

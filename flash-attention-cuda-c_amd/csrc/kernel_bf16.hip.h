@@ -19,7 +19,7 @@
 // Optimistic max.  exp2 / bf16 / f32 accumulation have ~2^127 of headroom, so the first pass takes
 // every exponential relative to the row max of tile 0 and issues no per-tile max, decision or rescale
 // (-4.5 % time).  If a later score exceeds that reference by more than the headroom (or P.V overflows),
-// l or O becomes inf/NaN; each lane tests that at the end of the pass, __syncthreads_or makes it
+// l or O becomes inf/NaN; each lane tests that at the end of the pass, block_or makes it
 // workgroup-uniform, and the whole block is recomputed by the tracked pass (running max, lazy rescale
 // with threshold 2^THR), which is always safe.
 #pragma once
@@ -44,6 +44,9 @@ struct Opt {
                                  // problems with one 256-row unit per CU or fewer (fwd_mfma_pair_kernel)
     bool p_f16 = false;          // 16x16x32 engine: weights rounded to fp16 (11 significant bits) instead of bf16 (8), V staged as fp16, P.V
                                  // on v_mfma_f32_16x16x32_f16 (needs |V| <= 65504): FA_FLAG_F16_WEIGHTS, and by default the query blocks whose rows see few keys
+    int stag = 0;                // half-step stagger of the two waves of a SIMD (LDS-DMA kernels, 8 waves): 1 = waves 4-7 run half a tile step
+                                 // behind waves 0-3 (their workgroup barrier sits between phase A and phase B), 2 = waves 0-3 behind waves 4-7.
+                                 // A wave in phase A (K reads, exponentials) then always shares its SIMD with one in phase B (attention_pass_stag)
 };
 
 template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, Opt O = Opt{}>
@@ -88,11 +91,21 @@ struct KernelCfg {
     static constexpr int QBLK = 32 * NWAVES;         // query rows of a unit
     static constexpr int RING = 3;                   // LDS ring slots: tile t+2 is staged in iteration t
     static constexpr int RING_BYTES = RING * TileGeom<D_, ESZ_>::SLOT;
+    // Staggered kernels: the lagging waves read V(t-1) in the barrier interval in which the leading ones read V(t), so the same 3 slots
+    // are cut as a K ring of 2 (K(t) in the K half of slot t & 1) and a V ring of 4 (the V halves of slots 0, 1 and the two halves
+    // of slot 2): tile t+2 still arrives in interval t, into places whose last readers left at the previous barrier
+    static constexpr int STAG = (DMA && O.waves == 8) ? O.stag : 0;
+    static_assert(O.stag == 0 || (DMA && O.waves == 8), "the stagger is built for the LDS-DMA kernels with 8 waves");
+    // query rows of a wave inside its unit: under the causal mask the LAGGING half takes the rows that see fewer keys (its tail hides
+    // behind the leading half's diagonal tiles)
+    __host__ __device__ static constexpr int row_group(int wave) { return (STAG == 1 && CAUSAL_) ? ((wave + O.waves / 2) & (O.waves - 1)) : wave; }
     // LDS-DMA staging: the epilogue regions (QBLK rows of D 2-byte outputs, or of 64 floats) sit behind ring slot 0
     static constexpr int EP_OFF = (DMA || DMA_K8) ? TileGeom<D_, ESZ_>::SLOT : 0;
     static constexpr int EP_NEED = EP_OFF + (sizeof(OutT_) == 2 ? QBLK * D_ * 2 : QBLK * 256);
-    static constexpr int LDS_BYTES = EP_NEED > RING_BYTES ? EP_NEED : RING_BYTES;
-    static_assert(LDS_BYTES <= 163840 - 256, "160 KiB of LDS per CU, 256 bytes of which __syncthreads_or takes statically");
+    static constexpr int DUMP_OFF = EP_NEED > RING_BYTES ? EP_NEED : RING_BYTES;   // the stagger's dump slot: behind the ring AND the epilogue regions
+    static constexpr int FLAG_OFF = DUMP_OFF + (STAG ? TileGeom<D_, ESZ_>::SLOT : 0);   // one word per wave: "my result is not finite" (block_or)
+    static constexpr int LDS_BYTES = FLAG_OFF + 64;
+    static_assert(LDS_BYTES <= 163840, "160 KiB of LDS per CU");
 };
 
 // What the library launches.
@@ -107,13 +120,32 @@ using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, Opt{.stamp = STAMP, .pad = PAD, 
 template <int D, bool CAUSAL, typename OutT>
 using P16Cfg = KernelCfg<D, CAUSAL, OutT, 2, Opt{.sum_mfma = 0, .p_f16 = true}>;
 
+// Workgroup-wide OR of a per-lane predicate through one LDS word per wave and ONE barrier.  (__syncthreads_or takes two barriers, 256
+// bytes of static LDS and -- it linearises threadIdx.y / .z -- two registers that hipcc spills to scratch in the largest kernels.)
+// A wave rewrites its word only a pass later, with at least two workgroup barriers in between: every wave has read by then.
+template <int NWAVES>
+__device__ __forceinline__ bool block_or(bool v, lds_ptr flags, int wave) {
+    const uint32_t mine = __any(v) ? 1u : 0u;                                    // wave-uniform
+    *reinterpret_cast<FA_LDS uint32_t*>(flags + 4 * wave) = mine;               // (all lanes: same address, same value)
+    __syncthreads();
+    u32x4 a = *reinterpret_cast<FA_LDS const u32x4*>(flags);
+    uint32_t r = a[0] | a[1] | a[2] | a[3];
+    if constexpr (NWAVES == 8) {
+        const u32x4 b = *reinterpret_cast<FA_LDS const u32x4*>(flags + 16);
+        r |= b[0] | b[1] | b[2] | b[3];
+    }
+    return __builtin_amdgcn_readfirstlane(r) != 0;
+}
+
 // The per-wave compute engine of a configuration: 16x16x32 MFMAs (computers16.hip.h) or 32x32x16 (computers.hip.h).
 template <class C>
 using WaveComputeOf = std::conditional_t<C::M16, WaveCompute16<C>, WaveCompute<C>>;
 
-// One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the
-// result has to be recomputed with max tracking (only ever true for TRACK = false).
-template <class C, bool TRACK>
+// One pass over all KV tiles of the workgroup's query block.  Returns (workgroup-uniform) whether the result is not finite and
+// has to be recomputed by a safer pass: the optimistic pass (TRACK = false) always reports, the tracked pass of an fp16-weights
+// kernel reports too (F16W: its V is fp16, where a finite bf16 |v| > 65504 is inf -- run_units then repeats the unit with bf16
+// weights and bf16 V, F16W = false, which is the last resort and reports nothing).
+template <class C, bool TRACK, bool F16W = C::P_F16>
 __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>& w, typename WaveComputeOf<C>::Stage& st, lds_ptr smem,
                                                int n_tiles, int my_tiles, int q_row0, int lane,
                                                unsigned long long (&acc)[24], bool tile0_in_flight) {
@@ -135,7 +167,8 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
     // Prologue: tile 0 (requested by the caller together with Q on the first pass) -> LDS, barrier; then
     // tile 1 is fetched while S(0) = K(0).Q^T and its row max are computed.
     if (!tile0_in_flight) st.load_all_into(0, smem);
-    st.write_all(smem);
+    if constexpr (C::P_F16) st.template write_all<0, F16W>(smem);
+    else st.write_all(smem);
     unsigned long long tw0 = 0;
     if constexpr (C::STAMP) tw0 = cycle_stamp();
     st.wait_all();
@@ -149,7 +182,8 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
         if (needs_mask(0)) w.mask(sA, 0, q_row0, S, lane);
         w.first_max(sA, c);   // m = row max of tile 0 (the reference of the optimistic pass)
     }
-    st.write_all(smem + SLOT);
+    if constexpr (C::P_F16) st.template write_all<0, F16W>(smem + SLOT);
+    else st.write_all(smem + SLOT);
     st.wait_all();
     __syncthreads();
     if constexpr (C::STAMP) { tp2 = cycle_stamp(); acc[8] += tp1 - tp0; acc[9] += tp2 - tp1; }
@@ -163,11 +197,16 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
         if constexpr (C::STAMP) t0 = cycle_stamp();
         if (kind != 2) {
             const bool has_next = kind == 0;
-            w.template tile_step<TRACK>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
-                                        has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
+            if constexpr (C::P_F16)
+                w.template tile_step<TRACK, F16W>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
+                                                  has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
+            else
+                w.template tile_step<TRACK>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
+                                            has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
         } else {
             st.load_all_into(t + AHEAD, smem + so_wr);
-            st.write_all(smem + so_wr);
+            if constexpr (C::P_F16) st.template write_all<0, F16W>(smem + so_wr);
+            else st.write_all(smem + so_wr);
         }
         if constexpr (C::STAMP) t4 = cycle_stamp();
         st.wait_all();   // (LDS-DMA staging: this wave's pieces of tile t + AHEAD have landed)
@@ -187,11 +226,118 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
         step(t, kind_of(t), sA, sB);
         if (t + 1 < n_tiles) step(t + 1, kind_of(t + 1), sB, sA);
     }
+    if constexpr (TRACK && !(C::P_F16 && F16W)) return false;
+    else {
+        unsigned long long tc0 = 0;
+        if constexpr (C::STAMP) tc0 = cycle_stamp();
+        const bool bad = block_or<C::NWAVES>(my_tiles > 0 && w.not_finite(), smem + C::FLAG_OFF, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+        if constexpr (C::STAMP) acc[10] += cycle_stamp() - tc0;
+        return bad;
+    }
+}
+
+// The staggered form of attention_pass (KernelCfg::STAG).  The two waves of a SIMD run the same program; in attention_pass both enter
+// phase A behind the barrier together, compete for the SIMD's vector issue through its exponentials and K reads (the younger wave's phase
+// A takes 1.25 x the older one's) and meet again at the next barrier, where the older wave waits 600-700 cycles per tile.  Here half of
+// the waves (LAG) run HALF A TILE STEP behind the others: their barrier sits between phase A and phase B,
+//     leading waves:   A(t) B(t) | barrier | A(t+1) B(t+1) | barrier ...
+//     lagging waves:        A(t) | barrier | B(t) A(t+1)   | barrier | B(t+1) ...
+// so a wave in phase A always shares its SIMD with a wave in phase B.  Same instruction sequence per wave, same results bit for bit.
+// What moves is which LDS tiles are live together: in interval t the leading waves read K(t+1), V(t), the lagging ones V(t-1), K(t+1),
+// and tile t+2 arrives -- hence the K ring of 2 and V ring of 4 (KernelCfg::STAG).  A lagging wave issues its DMA pieces at the START of
+// an interval like everyone else, i.e. in its phase B: B(t) carries tile t+3 (its pieces of tile 2 go out behind the prologue), and only
+// while a barrier still follows (t + 1 < n_tiles): the last B runs behind the pass's last barrier.
+template <class C, bool TRACK, bool LAG>
+__device__ __forceinline__ bool attention_pass_stag(const Params& p, WaveComputeOf<C>& w, typename WaveComputeOf<C>::Stage& st, lds_ptr smem,
+                                                    int n_tiles, int my_tiles, int q_row0, int lane,
+                                                    unsigned long long (&acc)[24], bool tile0_in_flight) {
+    using G = TileGeom<C::D, C::ESZ>;
+    using WC = WaveComputeOf<C>;
+    constexpr bool CAUSAL = C::CAUSAL;
+    constexpr int KVBLK = 64, SLOT = G::SLOT, KT = G::K_TILE, VT = G::V_TILE;
+    static_assert(KT == VT && WC::Stage::K_DMA, "K ring of 2 + V ring of 4 in three [K | V] slots");
+    auto k_img = [&](int t) { return smem + (t & 1) * SLOT; };
+    auto v_img = [&](int t) { return smem + ((t & 2) ? 2 * SLOT + (t & 1) * VT : (t & 1) * SLOT + KT); };
+    const int S = p.Sk;   // key bound of the masks
+    unsigned long long tp0 = 0, tp1 = 0, tp2 = 0;
+    if constexpr (C::STAMP) tp0 = cycle_stamp();
+    w.init();
+    constexpr int KBLK = (G::ROWB / 16) * 128;
+    const int kbase = C::M16 ? kd16_read_base(lane, KBLK) : kd_read_base(lane, KBLK);
+    const int vbase = C::M16 ? v16_read_base<C::D>(lane) : v_read_base(lane);
+    const float c = p.scale_log2;
+    auto needs_mask = [&](int t) { return (CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > S); };
+    typename WC::ScoresT sA, sB;
+
+    // Prologue, as in attention_pass: tile 0 = [K slot 0 | V slot 0], tile 1 = [K slot 1 | V slot 1]
+    if (!tile0_in_flight) st.load_all_into(0, smem);
+    unsigned long long tw0 = 0;
+    if constexpr (C::STAMP) tw0 = cycle_stamp();
+    st.wait_all();
+    if constexpr (C::STAMP) acc[16] += cycle_stamp() - tw0;
+    __syncthreads();
+    st.load_all_into(1, smem + SLOT);
+    if constexpr (C::STAMP) tp1 = cycle_stamp();
+    if (my_tiles > 0) {
+        w.qk_all(smem, kbase, sA);
+        if (needs_mask(0)) w.mask(sA, 0, q_row0, S, lane);
+        w.first_max(sA, c);
+    }
+    st.wait_all();
+    __syncthreads();
+    if constexpr (LAG) st.load_all_into2(2, k_img(2), v_img(2));   // K slot 0 is free behind this barrier: every wave has scored tile 0
+    if constexpr (C::STAMP) { tp2 = cycle_stamp(); acc[8] += tp1 - tp0; acc[9] += tp2 - tp1; }
+
+    // kind: 0 = full step, 1 = the wave's last tile, 2 = staging only (attention_pass)
+    auto step = [&](int t, int kind, typename WC::ScoresT& cur, typename WC::ScoresT& nxt) {
+        unsigned long long t0 = 0, ta = 0, t4 = 0, t6 = 0;
+        if constexpr (C::STAMP) t0 = cycle_stamp();
+        const bool has_next = kind == 0;
+        const bool mask_next = has_next && needs_mask(t + 1);
+        if constexpr (!LAG) {
+            st.set_dst2(k_img(t + 2), v_img(t + 2));
+            if (kind != 2) {
+                w.template tile_a<true>(st, t + 2, k_img(t + 1), v_img(t), kbase, vbase, c, cur, nxt);
+                if constexpr (C::STAMP) ta = w.t_mid;
+                w.template tile_b<TRACK, false>(st, t + 2, smem, v_img(t), vbase, c, cur, nxt, has_next, mask_next, (t + 1) * KVBLK, q_row0, S, lane);
+            } else {
+                st.load_all(t + 2);
+            }
+            if constexpr (C::STAMP) t4 = cycle_stamp();
+            st.wait_all();
+            __syncthreads();
+            if constexpr (C::STAMP) {
+                t6 = cycle_stamp();
+                if (kind != 2) { acc[1] += ta - t0; acc[2] += w.t_end - ta; acc[3] += t4 - w.t_end; acc[6] += 1; }
+                acc[5] += t6 - t4;
+            }
+        } else {
+            if (kind != 2) w.template tile_a<false>(st, 0, k_img(t + 1), v_img(t), kbase, vbase, c, cur, nxt);
+            if constexpr (C::STAMP) t4 = cycle_stamp();
+            st.wait_all();   // (the pieces issued in the previous phase B)
+            __syncthreads();
+            if constexpr (C::STAMP) t6 = cycle_stamp();
+            // the last B of the pass runs behind its last barrier: its pieces (nobody needs them) go to a dump region behind the ring
+            const bool dma = t + 1 < n_tiles;
+            st.set_dst2(dma ? k_img(t + 3) : smem + C::DUMP_OFF, dma ? v_img(t + 3) : smem + C::DUMP_OFF + KT);
+            if (kind != 2) w.template tile_b<TRACK, true>(st, t + 3, smem, v_img(t), vbase, c, cur, nxt, has_next, mask_next, (t + 1) * KVBLK, q_row0, S, lane);
+            else st.load_all(t + 3);
+            if constexpr (C::STAMP) {
+                if (kind != 2) { acc[1] += t4 - t0; acc[2] += w.t_end - t6; acc[3] += cycle_stamp() - w.t_end; acc[6] += 1; }
+                acc[5] += t6 - t4;
+            }
+        }
+    };
+    auto kind_of = [&](int t) { return t + 1 < my_tiles ? 0 : (t < my_tiles ? 1 : 2); };
+    for (int t = 0; t < n_tiles; t += 2) {
+        step(t, kind_of(t), sA, sB);
+        if (t + 1 < n_tiles) step(t + 1, kind_of(t + 1), sB, sA);
+    }
     if constexpr (TRACK) return false;
     else {
         unsigned long long tc0 = 0;
         if constexpr (C::STAMP) tc0 = cycle_stamp();
-        const bool bad = __syncthreads_or(my_tiles > 0 && w.not_finite()) != 0;
+        const bool bad = block_or<C::NWAVES>(my_tiles > 0 && w.not_finite(), smem + C::FLAG_OFF, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
         if constexpr (C::STAMP) acc[10] += cycle_stamp() - tc0;
         return bad;
     }
@@ -234,7 +380,7 @@ struct UnitCtx {
         Vh = (const char*)p.V + (b * p.vB + h * p.vH) * ESZ;
         Oh = (char*)p.O + (b * p.oB + h * p.oH) * (int64_t)sizeof(typename C::OutT);
         lse_head = p.lse ? p.lse + (int64_t)g * p.S : nullptr;
-        q_row0 = qb * QBLK + wave * WROWS;              // first query row of this wave
+        q_row0 = qb * QBLK + C::row_group(wave) * WROWS; // first query row of this wave
         const int q_end = min(p.S, (qb + 1) * QBLK);    // one past the last query row of the block
         const int k_tiles = (p.Sk + KVBLK - 1) / KVBLK;
         n_tiles = C::CAUSAL ? min(k_tiles, (q_end + KVBLK - 1) / KVBLK) : k_tiles;
@@ -312,8 +458,27 @@ __device__ __forceinline__ void run_units(const Params& p, const UnitList& L, ld
         // An opaque copy of the lane id keeps them inside the pass.
         int lane_p = lane;
         asm volatile("" : "+v"(lane_p));
-        if (attention_pass<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true))
-            attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false);
+        if constexpr (C::STAG != 0) {
+            // (wave-uniform: `wave` comes out of readfirstlane.  Both branches hold the same number of barriers.)
+            const bool lag = (wave >= C::NWAVES / 2) == (C::STAG == 1);
+            bool again;
+            if (lag) again = attention_pass_stag<C, false, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true);
+            else again = attention_pass_stag<C, false, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true);
+            if (again) {
+                if (lag) attention_pass_stag<C, true, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false);
+                else attention_pass_stag<C, true, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false);
+            }
+        } else if constexpr (C::P_F16) {
+            // fp16 weights need V in fp16: a finite bf16 |v| > 65504 is inf there (and 0 * inf = NaN poisons rows that do not even see
+            // the key).  Both fp16 passes report a non-finite result; the last resort is the bf16-weights tracked pass, which holds
+            // whatever bf16 holds (the reference's V is float: kernels/FlashAttention.cuh:60).  Data that never overflows pays nothing.
+            if (attention_pass<C, false, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true))
+                if (attention_pass<C, true, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false))
+                    attention_pass<C, true, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false);
+        } else {
+            if (attention_pass<C, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true))
+                attention_pass<C, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false);
+        }
 
         // The next unit's tile 0 and Q are requested ahead, so that their HBM round trip runs under this unit's epilogue
         // (every wave is past the last tile's barrier: ring slot 0 is free, the epilogue works behind it; the register-staged

@@ -197,9 +197,11 @@ struct BufStage {
     }
     // LDS write #N: the K writes, then the V writes.  K image: +8 keys = +128 B, +8 chunks = +8 KiB.
     // V image: +8 keys = +DB*512 B, +8 bf16 chunks = +1 KiB.
-    template <int N>
-    __device__ __forceinline__ void write(lds_ptr slot_base) const { write_from<N>(r, slot_base); }
-    template <int N>
+    // F16: convert bf16 V to fp16 on the way (the class's VF16 unless the caller says otherwise: the fp16-weights kernels' bf16-weights
+    // fallback pass, computers16.hip.h, writes the same image unconverted)
+    template <int N, bool F16 = VF16>
+    __device__ __forceinline__ void write(lds_ptr slot_base) const { write_from<N, F16>(r, slot_base); }
+    template <int N, bool F16 = VF16>
     __device__ __forceinline__ void write_from(const u32x4 (&r)[NL], lds_ptr slot_base) const {
         if constexpr (N < LOADS) {
             constexpr int gi = N / HALVES, hf = N % HALVES;
@@ -207,7 +209,7 @@ struct BufStage {
         } else if constexpr (ESZ == 2) {
             constexpr int n = N - LOADS, gi = n / HALVES, hf = n % HALVES;
             const u32x4 v = PAD ? keep_if(vok[hf], r[N]) : r[N];
-            lds_write_b128(slot_base + G::K_TILE, vlds + gi * (G::DB * 512) + hf * 1024, VF16 ? bf16x8_to_f16x8(v) : v);
+            lds_write_b128(slot_base + G::K_TILE, vlds + gi * (G::DB * 512) + hf * 1024, F16 ? bf16x8_to_f16x8(v) : v);
         } else {
             // fp8 V (ROWB = 128, one half): 16 e4m3fn bytes -> 16 bf16 (exact), two adjacent 16-byte chunks
             constexpr int n = (N - LOADS) / 2, W = (N - LOADS) % 2;   // load n of this tensor, low / high 8 bytes
@@ -218,7 +220,7 @@ struct BufStage {
     template <int N = 0> __device__ __forceinline__ void load_all_to(u32x4 (&dst)[NL], int t) const { if constexpr (N < NL) { load_to<N>(dst, t); load_all_to<N + 1>(dst, t); } }
     template <int N = 0> __device__ __forceinline__ void write_all_from(const u32x4 (&src)[NL], lds_ptr s) const { if constexpr (N < NW) { write_from<N>(src, s); write_all_from<N + 1>(src, s); } }
     template <int N = 0> __device__ __forceinline__ void load_all(int t) { if constexpr (N < NL) { load<N>(t); load_all<N + 1>(t); } }
-    template <int N = 0> __device__ __forceinline__ void write_all(lds_ptr s) const { if constexpr (N < NW) { write<N>(s); write_all<N + 1>(s); } }
+    template <int N = 0, bool F16 = VF16> __device__ __forceinline__ void write_all(lds_ptr s) const { if constexpr (N < NW) { write<N, F16>(s); write_all<N + 1, F16>(s); } }
     // (interface shared with DmaStage, whose loads need their LDS destination)
     __device__ __forceinline__ void set_dst(lds_ptr) {}
     __device__ __forceinline__ void load_all_into(int t, lds_ptr) { load_all(t); }
@@ -262,7 +264,7 @@ struct DmaStage {
     int ktile, vtile;      // bytes per 64-key tile step (scalar)
     int kgrp, vgrp;        // bytes per 8-key group step in global memory (scalar)
     int kdst, vdst;        // this wave's first block inside the K / V image (scalar)
-    uint32_t dst;          // LDS byte address of the ring slot the next loads go to (scalar)
+    uint32_t dst, dstv;    // LDS byte addresses of the K image / the V image the next loads go to (scalar)
     __device__ __forceinline__ static u32x4 descriptor(uint64_t a, uint32_t bytes) {
         return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
     }
@@ -281,9 +283,11 @@ struct DmaStage {
         voff = V16 ? (8 * g0 + ((lane >> 1) & 7)) * (int)vS_bytes + (2 * (lane >> 4) + (lane & 1)) * 16
                    : (8 * g0 + ((lane >> 2) & 7)) * (int)vS_bytes + (4 * (lane >> 5) + (lane & 3)) * 16;
         kdst = g0 * KBLK;
-        vdst = G::K_TILE + g0 * VBLK;
+        vdst = g0 * VBLK;
     }
-    __device__ __forceinline__ void set_dst(lds_ptr slot) { dst = (uint32_t)(uintptr_t)slot; }
+    // a ring slot [K image | V image], or (the staggered kernels' K ring of 2 + V ring of 4: kernel_bf16.hip.h) the two images on their own
+    __device__ __forceinline__ void set_dst(lds_ptr slot) { set_dst2(slot, slot + G::K_TILE); }
+    __device__ __forceinline__ void set_dst2(lds_ptr kimg, lds_ptr vimg) { dst = (uint32_t)(uintptr_t)kimg; dstv = (uint32_t)(uintptr_t)vimg; }
     // The DMA is issued from inline asm: hipcc then keeps no account of it -- issued through the builtin, every ds_read_b64_tr_b16 that
     // follows waits vmcnt(0) for it (the V^T reads of the SAME iteration), because the waitcnt pass cannot tell the ring slots apart.
     // Ordering is by hand instead: wait_all() before the barrier that publishes the tile.  M0 (the LDS destination) is written in the
@@ -302,7 +306,7 @@ struct DmaStage {
     __device__ __forceinline__ void load(int t) const {
         constexpr int n = N < LOADS ? N : N - LOADS, gi = n / HALVES, j = n % HALVES;
         if constexpr (N < LOADS) dma16(krsrc, dst + kdst + gi * KBLK + j * 1024, koff[gi] + t * ktile + j * 128);
-        else dma16(vrsrc, dst + vdst + gi * VBLK + j * 1024, voff + t * vtile + gi * vgrp + j * 128);
+        else dma16(vrsrc, dstv + vdst + gi * VBLK + j * 1024, voff + t * vtile + gi * vgrp + j * 128);
     }
     // every piece this wave has issued has landed in LDS (then a barrier publishes it to the other waves)
     __device__ __forceinline__ void wait_all() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -310,6 +314,7 @@ struct DmaStage {
     __device__ __forceinline__ void write(lds_ptr) const {}
     template <int N = 0> __device__ __forceinline__ void load_all(int t) const { if constexpr (N < NL) { load<N>(t); load_all<N + 1>(t); } }
     __device__ __forceinline__ void load_all_into(int t, lds_ptr slot) { set_dst(slot); load_all(t); }
+    __device__ __forceinline__ void load_all_into2(int t, lds_ptr kimg, lds_ptr vimg) { set_dst2(kimg, vimg); load_all(t); }
     __device__ __forceinline__ void write_all(lds_ptr) const {}
 };
 

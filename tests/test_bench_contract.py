@@ -157,3 +157,65 @@ def test_gpus_must_match_the_world():
     env = dict(_clean_env(), RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_roofline_kernel_name_comes_from_the_plan():
+    """roofline.kernel is what the library's own plan says the call launches (flash_attention_plan_ex), per workload: the
+    fused two-precision launch for the causal headline (rocprofv3 names it fa::fwd_mfma_dual_kernel:
+    profiles/r03_kernel_stats_cfg2.csv), the single persistent kernel without the mask, the pair kernel for cfg1's shape under the mask."""
+    import __graft_entry__ as entry
+    fa = entry.load_package()
+    want = {"cfg2": "fa::fwd_mfma_dual_kernel", "cfg2nc": "fa::fwd_mfma_kernel", "cfg1": "fa::fwd_mfma_kernel", "cfg1c": "fa::fwd_mfma_pair_kernel",
+            "cfg4": "fa::fwd_mfma_kernel", "cfg3": "fa::fwd_mfma_kernel", "anchor": "fa::fwd_mfma_kernel"}
+    for wl, name in want.items():
+        B, H, S, d, causal, _ = bench.WORKLOADS[wl]
+        dt = fa.FA_DTYPE_FP8_E4M3 if wl == "cfg3" else fa.FA_DTYPE_BF16
+        assert bench.launched_kernel(fa, B * H, 1, S, d, causal, dt, fa.FA_DTYPE_F32, 0) == name, wl
+    # one precision on every row: a single kernel again
+    B, H, S, d, causal, _ = bench.WORKLOADS["cfg2"]
+    assert bench.launched_kernel(fa, B * H, 1, S, d, causal, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, fa.FA_FLAG_BF16_WEIGHTS) == "fa::fwd_mfma_kernel"
+    # and the dry-run line carries it, with the traffic ratio's slot, for the headline and the cfg4 sub-record
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--dry-run", "--no-ceiling"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["roofline"]["kernel"] == "fa::fwd_mfma_dual_kernel" and "traffic_ratio" in line["roofline"]
+    assert line["cfg4"]["roofline"]["kernel"] == "fa::fwd_mfma_kernel"
+
+
+def test_anchor_workload_line():
+    """`--workload anchor`: bf16 in AND out, non-causal, S = 2048, d = 128, 2048 units -- the shape class of the guide's best known-good
+    structure (1.25 PFLOP/s); the line says how far from it the run is."""
+    import subprocess
+    import sys
+    B, H, S, d, causal, _ = bench.WORKLOADS["anchor"]
+    assert (S, d, causal) == (2048, 128, False) and B * H * (S // 256) >= 2048
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "anchor", "--steps", "2", "--warmup", "1", "--dry-run", "--no-ceiling",
+                        "--no-cfg4"], env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["config"]["out_dtype"] == "bf16" and line["anchor"]["guide_best_known_tflops"] == 1250.0 and "ratio_to_guide" in line["anchor"]
+    assert "bf16_out" not in line
+
+
+def test_more_ranks_than_visible_gpus_is_refused_before_any_rendezvous():
+    """`--gpus N` with fewer than N GPUs visible: one stated line, exit status 4, nothing started (no torchrun child, no
+    init_process_group) -- from the parent of an N-rank run and from a rank started under someone else's torchrun alike.  The count is
+    injected (this box has no GPU): FA_BENCH_VISIBLE_DEVICES."""
+    import subprocess
+    import sys
+    import time
+    exe = [sys.executable, os.path.join(ROOT, "bench.py")]
+    t0 = time.time()
+    r = subprocess.run(exe + ["--gpus", "8", "--dry-run"], env=dict(_clean_env(), FA_BENCH_VISIBLE_DEVICES="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 4 and "--gpus 8 but only 1 GPU(s) visible" in r.stderr and r.stdout.strip() == "", (r.returncode, r.stderr[-500:])
+    assert time.time() - t0 < 60
+    env = dict(_clean_env(), RANK="1", WORLD_SIZE="2", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29998", FA_BENCH_VISIBLE_DEVICES="1")
+    r = subprocess.run(exe + ["--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)   # (would hang in the rendezvous otherwise)
+    assert r.returncode == 4 and "only 1 GPU(s) visible" in r.stderr
+    # enough devices: goes on as before
+    r = subprocess.run(exe + ["--gpus", "1", "--steps", "2", "--warmup", "1", "--dry-run", "--no-ceiling", "--no-cfg4", "--no-bf16-out"],
+                       env=dict(_clean_env(), FA_BENCH_VISIBLE_DEVICES="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
