@@ -52,10 +52,32 @@ tests/fa_tune: tests/fa_tune.hip $(KHDR) oracle/liboracle_attention.so
 tests/micro/%: tests/micro/%.hip
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++20 -o $@ $<
 
+# Host-side sanitizers (there is no GPU ASan on this pool): the oracle under gcc's ASan + UBSan, and the library's
+# HOST code -- argument validation, make_plan, snake_imbalance, plan_ex, shard_range: everything callable without a GPU -- under clang's
+# (FlashAttention.hip rebuilt with -fsanitize=address,undefined; the kernel translation units are linked as built).  Each test file
+# runs in a process of its own with the matching runtime preloaded; tests/main.cpp (the C++ harness) is compiled and linked under the
+# same flags as a build check (running it needs a GPU).
+ASAN_DIR  := build/asan
+CLANG_ASAN_RT := $(shell /opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
+GCC_ASAN_RT   := $(shell gcc -print-file-name=libasan.so)
+SANFLAGS  := -fsanitize=address,undefined -fno-omit-frame-pointer -g
+asan: $(LIB) oracle
+	@mkdir -p $(ASAN_DIR)
+	gcc -O1 -march=x86-64-v3 -fopenmp -fPIC -Wall -Wextra -std=c11 $(SANFLAGS) -shared -o $(ASAN_DIR)/liboracle_attention.so oracle/cpu_attention.c -lm
+	$(HIPCC) $(HIPFLAGS) $(SANFLAGS) -fno-gpu-sanitize -shared-libsan -c -o $(ASAN_DIR)/FlashAttention.o $(PKG)/csrc/FlashAttention.hip
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared $(SANFLAGS) -shared-libsan -o $(ASAN_DIR)/libflash_attention.so $(ASAN_DIR)/FlashAttention.o $(filter-out build/obj/FlashAttention.o,$(KOBJ))
+	$(HIPCC) -O1 -std=c++17 $(SANFLAGS) -shared-libsan -o $(ASAN_DIR)/fa_test tests/main.cpp -L$(ASAN_DIR) -lflash_attention -Loracle -loracle_attention \
+	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../../oracle'
+	ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 LD_PRELOAD=$(GCC_ASAN_RT) \
+	    ORACLE_LIB_PATH=$(CURDIR)/$(ASAN_DIR)/liboracle_attention.so python -m pytest tests/test_oracle.py -q -p no:cacheprovider
+	ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 LD_PRELOAD=$(CLANG_ASAN_RT) \
+	    FA_LIB_PATH=$(CURDIR)/$(ASAN_DIR)/libflash_attention.so python -m pytest tests/test_abi.py tests/test_shard.py -q -p no:cacheprovider -m "not gpu"
+	@echo "asan: oracle (gcc ASan+UBSan) and library host code (clang ASan+UBSan) clean"
+
 asm: $(KSRC) $(KHDR)
 	mkdir -p build && $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/inst_bf16_d128.s $(PKG)/csrc/inst_bf16_d128.hip
 
 clean:
 	rm -f $(LIB) $(PKG)/fa_main tests/fa_test tests/fa_tune tests/unit_kernels tests/micro/simd_mix tests/micro/valu_rates tests/micro/atomic_latency oracle/liboracle_attention.so
 	rm -rf build
-.PHONY: all lib tune oracle clean asm
+.PHONY: all lib tune oracle clean asm asan

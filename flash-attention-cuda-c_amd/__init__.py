@@ -22,7 +22,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflash_attention.so")
+# FA_LIB_PATH: another build of the SAME library (the host-sanitizer build of `make asan`); there is still no other implementation
+LIB_PATH = os.environ.get("FA_LIB_PATH") or os.path.join(_HERE, "libflash_attention.so")
 
 FA_DTYPE_F32, FA_DTYPE_BF16, FA_DTYPE_FP8_E4M3, FA_DTYPE_F16 = 0, 1, 2, 3
 FA_FLAG_F16_WEIGHTS = 1     # flash_attention_ex: softmax weights rounded to fp16 on every row (bf16 inputs, d = 64 / 128)
@@ -166,7 +167,8 @@ def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None
     ``return_lse=True`` (LSE: fp32 [B, H, S], natural-log sum of exp(scale * scores) over the visible keys).
     ``weights_dtype`` (bf16 inputs): None = the library default (fp16 softmax weights on the rows that see fewer than
     FA_EARLY_KEYS keys, bf16 weights elsewhere); ``torch.float16`` = FA_FLAG_F16_WEIGHTS (fp16 weights on every row; d = 64
-    or 128); ``torch.bfloat16`` = FA_FLAG_BF16_WEIGHTS (bf16 weights on every row: the fastest form).
+    or 128); ``torch.bfloat16`` = FA_FLAG_BF16_WEIGHTS (bf16 weights on every row: the fastest form; accepted and ignored for
+    fp32 / fp8 inputs, which have one form).
     """
     import torch
     if not (Q.is_cuda and K.is_cuda and V.is_cuda):
@@ -192,7 +194,10 @@ def flash_attention(Q, K, V, O=None, scale=None, is_causal=False, out_dtype=None
         if weights_dtype == torch.float16:
             flags |= FA_FLAG_F16_WEIGHTS
         elif weights_dtype == torch.bfloat16:
-            flags |= FA_FLAG_BF16_WEIGHTS
+            # bf16 weights are what fp32 / fp8 inputs get anyway (one form each): the request is a no-op there, not an error --
+            # the library rejects the FLAG on non-bf16 inputs (FA_ERR_BAD_FLAGS), so it is only set where it selects something
+            if Q.dtype == torch.bfloat16:
+                flags |= FA_FLAG_BF16_WEIGHTS
         else:
             raise TypeError("weights_dtype must be torch.float16 or torch.bfloat16")
     with torch.cuda.device(Q.device):

@@ -44,6 +44,7 @@ struct Opt {
                                  // problems with one 256-row unit per CU or fewer (fwd_mfma_pair_kernel)
     bool p_f16 = false;          // 16x16x32 engine: weights rounded to fp16 (11 significant bits) instead of bf16 (8), V staged as fp16, P.V
                                  // on v_mfma_f32_16x16x32_f16 (needs |V| <= 65504): FA_FLAG_F16_WEIGHTS, and by default the query blocks whose rows see few keys
+    int prio_a = -1;             // phase A of a tile step at s_setprio 1 (-1: on)
     int stag = 0;                // half-step stagger of the two waves of a SIMD (LDS-DMA kernels, 8 waves): 1 = waves 4-7 run half a tile step
                                  // behind waves 0-3 (their workgroup barrier sits between phase A and phase B), 2 = waves 0-3 behind waves 4-7.
                                  // A wave in phase A (K reads, exponentials) then always shares its SIMD with one in phase B (attention_pass_stag)
@@ -60,7 +61,7 @@ struct KernelCfg {
     // exponentials) at s_setprio 1 and phase B (P.V) at 0: of the two waves of a SIMD the one still in phase A outranks the one ahead
     // of it.  +0.6 ... +1.3 % (causal and not, 21 / 15 interleaved rounds: profiles/r03_tune_j_phase_a_priority_*.log); static
     // priorities for one half of the waves measured nothing (r03_tune_e_*)
-    static constexpr bool PRIO_A = true;
+    static constexpr bool PRIO_A = O.prio_a != 0;
     // Cache policy of the output stores (utils.hip.h: store_global_b128): non-temporal under the causal mask -- O is written once and
     // never read, and every line it leaves in the XCD's L2 evicts K/V lines that the head's other query blocks are about to
     // re-read (causal, fp32 O: plain 1058, sc1 1073, nt 1076, sc0 sc1 1076 TFLOP/s; bf16 O +0.5 %; without the mask -0.3 %:

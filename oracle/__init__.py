@@ -24,7 +24,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle_attention.so")
+_LIB_PATH = os.environ.get("ORACLE_LIB_PATH") or os.path.join(_HERE, "liboracle_attention.so")   # (`make asan`: the sanitizer build)
 _lib = None
 
 _f32p = ctypes.POINTER(ctypes.c_float)

@@ -148,6 +148,8 @@ static std::vector<Variant> make_variants() {
     v.push_back({"fp32 O, STAGGER: waves 0-3 half a step behind", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = M, .stag = 2}>>, 4});
     v.push_back({"fp32 O, STAGGER (4-7 behind), the other engine", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = CAUSAL ? 1 : 0, .stag = 1}>>, 4});
     v.push_back({"fp32 O, the other engine", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = CAUSAL ? 1 : 0}>>, 4});
+    v.push_back({"fp32 O, STAGGER (4-7 behind), no phase priority", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = M, .prio_a = 0, .stag = 1}>>, 4});
+    v.push_back({"fp32 O, STAGGER (0-3 behind), no phase priority", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = M, .prio_a = 0, .stag = 2}>>, 4});
     v.push_back({"STAMP fp32 O, STAGGER: waves 4-7 half a step behind", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.stamp = true, .m16 = M, .stag = 1}>>, 4});
     return v;
 }

@@ -56,7 +56,10 @@ def test_baseline_cfg3_sampled():
                 rep = parity_report(got, ref)
                 print(f"cfg3 causal={causal} head {h} rows [{r0},{r1}): {rep}")
                 err = np.abs(got - ref)
-                assert (err <= 4e-3 + 4e-3 * np.abs(ref)).all(), rep
+                # the stated tolerance: rows of a non-causal S = 16384 problem see 16384 keys (measured max-abs 1.9e-4); under the mask the
+                # first rows see a handful, with bf16 weights (fp8 inputs have one weight precision): 4e-3 there, and said so
+                tol = 1e-3 if (not causal or r0 >= 8160) else 4e-3
+                assert (err <= tol + tol * np.abs(ref)).all(), rep
                 assert np.sqrt(np.mean(err ** 2)) <= 1e-3
             # LSE of the sampled rows (float64 restatement on the same inputs)
             r0, r1 = 16320, 16384
@@ -93,6 +96,19 @@ def test_baseline_cfg4_offsets():
             rep = parity_report(got, ref)
             print(f"cfg4 head {g} rows [{r0},{r1}): {rep}")
             assert (err <= 8e-3 + 8e-3 * np.abs(ref)).all(), rep      # bf16 P + bf16 O rounding
+    # the whole problem again with fp32 OUTPUT (8 GiB), at the stated tolerance 1e-3 + 1e-3|ref| (the bf16 output above cannot meet
+    # it: its half-ulp is 2^-9): heads 0, 1023, 1024, 2047, first / middle / last rows
+    O32 = fa.flash_attention(Q, K, V, is_causal=False, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    for g in (0, 1023, 1024, 2047):
+        Qh, Kh, Vh = (_head_to_host(t, g) for t in (Q, K, V))
+        for (r0, r1) in ((0, 64), (4064, 4128), (8128, 8192)):
+            ref = oracle.attention_rows(Qh, Kh, Vh, (0, 1), (r0, r1), causal=False)[0]
+            got = O32[g, 0, r0:r1].cpu().numpy()
+            rep = parity_report(got, ref)
+            print(f"cfg4 fp32 O head {g} rows [{r0},{r1}): {rep}")
+            assert rep["pass_frac_at_1e-3"] == 1.0, rep
+    del O32
     # heads are distinct draws: a wrapped offset would make head g alias head g - 1024 (or 0)
     assert not torch.equal(O[2047], O[1023]) and not torch.equal(O[1024], O[0])
     # rank 7's slab of the 8-way shard, as its own dense problem == the same heads of the full run, bit for bit

@@ -2,12 +2,14 @@
 minted from the reference's check.py, and size-independent properties at the BASELINE sizes.
 
 Tolerances (written here, justified in DESIGN.md "Tolerance"):
-  fp32 inputs  (exact-fp32 generic kernel):  |O - ref| <= 2e-5 + 1e-4 |ref|
-  bf16 inputs, fp32 O (MFMA kernel; P is rounded to bf16 before P.V -> 2^-9 relative per weight):
-               |O - ref| <= 4e-3 + 4e-3 |ref|   and   RMS error <= 1e-3
+  fp32 inputs  (exact-fp32 kernels):  |O - ref| <= 2e-5 + 1e-4 |ref|
+  bf16 inputs, fp32 O, the DEFAULT call on N(0,1) tensors:  the tolerance BASELINE.json / BASELINE.md state against check.py
+               (/root/reference/check.py:19-21),  |O - ref| <= 1e-3 + 1e-3 |ref|  on EVERY element (STATED below);
+  bf16 inputs, fp32 O, where the test says why: 4e-3 + 4e-3 |ref| (BF16W below) -- bf16 weights forced on every row
+               (weights_dtype=torch.bfloat16), head dimensions that run zero-padded (no fp16-weights kernel: their early rows keep
+               bf16 weights), fp8 inputs, or data spiked / scaled away from N(0,1) (the bound is a property of the data:
+               test_sharp_softmax_parity_is_what_it_measures);
   bf16 / f16 O add the output rounding (2^-9 / 2^-11 relative).
-BASELINE.json asks for rtol = 1e-3 against check.py; with bf16 operands that is not attainable
-element-wise: the RMS bound above is the 1e-3 statement that does hold.
 """
 import numpy as np
 import pytest
@@ -23,11 +25,19 @@ import oracle  # noqa: E402  (checker only)
 DEV = "cuda:0"
 
 
-def tol_for(in_dtype, out_dtype):
+STATED = (1e-3, 1e-3)     # what north_star states; the default call on N(0,1) data is held to it element-wise
+BF16W = (4e-3, 4e-3)      # bf16 weights on rows that see few keys / data away from N(0,1): each use says which
+
+
+def tol_for(in_dtype, out_dtype, weights=None, padded=False):
+    """(atol, rtol) of a call: fp32 inputs exact; bf16 / fp8 inputs at the default precision on randn data the STATED tolerance,
+    with bf16 weights forced (weights=torch.bfloat16), a zero-padded head dimension or fp8 inputs BF16W; plus the output's rounding."""
     if in_dtype == torch.float32:
         atol, rtol = 2e-5, 1e-4
+    elif weights == torch.bfloat16 or padded or in_dtype not in (torch.bfloat16,):
+        atol, rtol = BF16W
     else:
-        atol, rtol = 4e-3, 4e-3
+        atol, rtol = STATED
     if out_dtype == torch.bfloat16:
         atol, rtol = atol + 4e-3, rtol + 4e-3
     if out_dtype == torch.float16:
@@ -144,7 +154,7 @@ def test_golden_bf16_inputs(golden):
         np.testing.assert_array_equal(t.float().numpy(), golden.load("F5bf16", k))   # exact in bf16
     out, _ = fa.multi_head_attention(Q.to(DEV), K.to(DEV), V.to(DEV), 1, out_dtype=torch.float32)
     torch.cuda.synchronize()
-    check(out.cpu().numpy(), golden.load("F5bf16", "out"), 4e-3, 4e-3, rms=1e-3)
+    check(out.cpu().numpy(), golden.load("F5bf16", "out"), *STATED, rms=1e-3)
 
 
 def test_golden_layout_bf16_two_heads(golden):
@@ -153,7 +163,7 @@ def test_golden_layout_bf16_two_heads(golden):
     ref, _ = oracle.multi_head_attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), 2)
     out, _ = fa.multi_head_attention(Q.to(DEV), K.to(DEV), V.to(DEV), 2, out_dtype=torch.float32)
     torch.cuda.synchronize()
-    check(out.cpu().numpy(), ref, 4e-3, 4e-3, rms=1e-3)
+    check(out.cpu().numpy(), ref, *STATED, rms=1e-3)
 
 
 # ------------------------------------------------------------------ random parity vs the oracle
@@ -181,7 +191,8 @@ BF16_CASES = [(1, 1, 64, 128, False), (1, 2, 256, 128, False), (2, 2, 512, 128, 
 def test_bf16_path_matches_oracle(B, H, S, d, causal):
     Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in (4, 5, 6))
     ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=causal)
-    atol, rtol = tol_for(torch.bfloat16 if d <= 128 else torch.float32, torch.float32)   # d <= 128: MFMA path (bf16 P)
+    # d <= 128: MFMA path, default precision; d = 80: zero-padded onto the d = 128 instantiation, whose early rows keep bf16 weights
+    atol, rtol = tol_for(torch.bfloat16 if d <= 128 else torch.float32, torch.float32, padded=d not in (64, 128))
     check(run_gpu(Q, K, V, causal), ref, atol, rtol, rms=1e-3)
 
 
@@ -200,7 +211,7 @@ def test_causal_edges():
     np.testing.assert_allclose(O[:, :, 0], V.float().numpy()[:, :, 0], rtol=1e-6, atol=1e-6)
     ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=True)
     for r in (31, 32, 63, 64, 255, 256, 511):
-        check(O[:, :, r], ref[:, :, r], 4e-3, 4e-3)
+        check(O[:, :, r], ref[:, :, r], *STATED)
 
 
 def test_online_softmax_rescale_is_forced():
@@ -212,7 +223,7 @@ def test_online_softmax_rescale_is_forced():
         K[:, :, key] = (6.0 * Q[:, :, row].float()).to(torch.bfloat16)
     for causal in (False, True):
         ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=causal)
-        check(run_gpu(Q, K, V, causal), ref, 4e-3, 4e-3, rms=1e-3)
+        check(run_gpu(Q, K, V, causal), ref, *BF16W, rms=1e-3)      # (spiked data: a row's mass on ONE key, its rounding does not average out)
 
 
 def test_large_score_range_no_overflow():
@@ -426,7 +437,8 @@ def test_fuzz_shapes_layouts_dtypes(i, dtype, B, H, Sq, Sk, d, causal, strided, 
     torch.cuda.synchronize()
     f = lambda t, S: view(t, S).float().numpy()
     ref = oracle.attention_numpy(f(Qm, Sq), f(Km, Sk), f(Vm, Sk), causal=causal)
-    atol, rtol = tol_for(torch.float32 if dtype == torch.float32 else torch.bfloat16, out_dtype)
+    # bf16 at d in {64, 128}: the default precision; other d run zero-padded (bf16 weights on the early rows), d > 128 the exact generic kernel
+    atol, rtol = tol_for(torch.float32 if (dtype == torch.float32 or d > 128) else torch.bfloat16, out_dtype, padded=d not in (64, 128) or dtype == FP8)   # (fp8 inputs: one weight precision, bf16)
     check(O.float().cpu().numpy(), ref, atol, rtol)
     np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(f(Qm, Sq), f(Km, Sk), causal=causal), rtol=2e-6,
                                atol=2e-4 if dtype == torch.float32 else 3e-3)
@@ -451,7 +463,7 @@ def test_bf16_head_dims_padded_onto_the_mfma_kernel(d, causal):
                 Qd, Kd, Vd = Qd.contiguous(), Kd.contiguous(), Vd.contiguous()
             O, lse = fa.flash_attention(Qd, Kd, Vd, is_causal=causal, out_dtype=out_dtype, return_lse=True)
             torch.cuda.synchronize()
-            atol, rtol = tol_for(torch.bfloat16, out_dtype)
+            atol, rtol = tol_for(torch.bfloat16, out_dtype, padded=True)     # (no fp16-weights kernel for zero-padded head dimensions)
             check(O.float().cpu().numpy(), ref, atol, rtol)
             np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(f(Qm, Sq), f(Km, Sk), causal=causal), rtol=2e-6, atol=3e-3)
     assert fa.plan(B, H, Sq, d, causal, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["kernel_id"] == 1
@@ -512,7 +524,7 @@ def test_padded_output_rows_are_not_overrun():
         torch.cuda.synchronize()
         assert bool((buf[..., d:] == 7.0).all())
         ref = oracle.attention(Q.float().cpu().numpy(), K.float().cpu().numpy(), V.float().cpu().numpy(), causal=True)
-        atol, rtol = tol_for(in_dtype, out_dtype)
+        atol, rtol = tol_for(in_dtype, out_dtype, padded=True)      # d = 72: zero-padded instantiation
         check(O.float().cpu().numpy(), ref, atol, rtol)
 
 
@@ -531,7 +543,7 @@ def test_custom_scale_and_nonpositive_scale_route():
     Q, K, V = (randn((1, 2, 192, 64), s, torch.bfloat16) for s in (22, 23, 24))
     for scale in (0.5, 0.03, -0.2, 0.0):   # scale <= 0 takes the generic kernel
         ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), scale=scale)
-        check(run_gpu(Q, K, V, False, scale=scale), ref, 4e-3, 4e-3)
+        check(run_gpu(Q, K, V, False, scale=scale), ref, *BF16W)   # (scale 0.5 = 4 / sqrt(d): a sharp softmax; scale <= 0: exact fp32 math)
 
 
 def test_every_output_element_is_written():
@@ -591,7 +603,7 @@ def _sampled_check(B, H, S, d, causal, seeds, heads, rows):
     for h0 in heads:
         for (r0, r1) in rows:
             ref = oracle.attention_rows(Qf, Kf, Vf, (h0, h0 + 1), (r0, r1), causal=causal)
-            check(Of[h0:h0 + 1, r0:r1], ref, 4e-3, 4e-3, rms=1e-3)
+            check(Of[h0:h0 + 1, r0:r1], ref, *STATED, rms=1e-3)
     return Q, K, V, O
 
 
@@ -605,7 +617,7 @@ def test_persistent_grid_every_unit_is_computed(B, H, S, d, causal, out_dtype):
     prefetched under the epilogue).  Full-tensor compare, so a skipped or doubly-assigned unit cannot hide."""
     Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in (95, 96, 97))
     ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=causal)
-    atol, rtol = tol_for(torch.bfloat16, out_dtype)
+    atol, rtol = tol_for(torch.bfloat16, out_dtype)           # (S < FA_EARLY_KEYS: fp16 weights on every row)
     check(run_gpu(Q, K, V, causal, out_dtype=out_dtype), ref, atol, rtol)
 
 
@@ -618,7 +630,7 @@ def test_persistent_grid_fallback_inside_a_walk():
         Q[0, h] *= 12
         K[0, h] *= 12
     ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=True)
-    check(run_gpu(Q, K, V, True), ref, 4e-3, 4e-3)
+    check(run_gpu(Q, K, V, True), ref, *BF16W)      # (four heads x12: scores ~ N(0, 144), far from the N(0,1) data the stated tolerance is for)
 
 
 def test_baseline_cfg1_full_tensor():
@@ -626,7 +638,7 @@ def test_baseline_cfg1_full_tensor():
     B, H, S, d = 4, 8, 2048, 64
     Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in (31, 32, 33))
     ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=False)
-    check(run_gpu(Q, K, V, False), ref, 4e-3, 4e-3, rms=1e-3)
+    check(run_gpu(Q, K, V, False), ref, *STATED, rms=1e-3)
 
 
 def test_baseline_cfg2_sampled_and_properties():
@@ -803,7 +815,7 @@ def test_pair_kernel_small_problems(B, H, Sq, Sk, d, causal, out_dtype, wd):
     O1 = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, out_dtype=out_dtype, weights_dtype=wd)
     torch.cuda.synchronize()
     assert torch.equal(O, O1)                                    # (one instantiation whether or not the LSE is asked for)
-    atol, rtol = tol_for(torch.bfloat16, out_dtype)
+    atol, rtol = tol_for(torch.bfloat16, out_dtype, weights=wd)
     check(O.float().cpu().numpy(), ref, atol, rtol)
     np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(Qf, Kf, causal=causal), rtol=2e-6, atol=2e-3)
     if out_dtype == torch.float32 and wd is None:
@@ -852,7 +864,7 @@ def test_parity_at_stated_tolerance_cfg1_full_tensor():
         O = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), out_dtype=torch.float32, weights_dtype=wd)
         torch.cuda.synchronize()
         rep = _parity_table(f"cfg1 weights={'fp16' if wd else 'bf16'}", O.cpu().numpy(), ref)
-        assert rep["pass_frac_at_1e-3"] >= 0.9999, rep
+        assert rep["pass_frac_at_1e-3"] == 1.0, rep
 
 
 def test_f16_weights_option_edges():
@@ -884,3 +896,106 @@ def test_f16_weights_option_edges():
         with pytest.raises(fa.FlashAttentionError) as e:
             fa.flash_attention(bad.to(DEV), bad.to(DEV), bad.to(DEV), weights_dtype=torch.float16)
         assert e.value.code == -8   # FA_ERR_BAD_FLAGS
+
+
+# ------------------------------------------------------------------ outside N(0,1): |V| beyond fp16, sharp softmax
+def _rel_check(O, ref, scale, atol, rtol):
+    """|O - ref| <= scale * (atol + rtol |ref / scale|): the stated form of the tolerance for values of magnitude `scale`."""
+    assert np.isfinite(O).all(), f"{(~np.isfinite(O)).sum()} non-finite outputs"
+    err = np.abs(O - ref)
+    bad = err > scale * atol + rtol * np.abs(ref)
+    assert not bad.any(), f"{bad.sum()} / {bad.size} outside tolerance, max abs err {err.max():.3e} (scale {scale:g})"
+
+
+@pytest.mark.parametrize("B,H,S,Sk,d,causal,k_big", [
+    (2, 64, 2048, 2048, 128, True, 700),     # persistent kernels, the fused two-precision launch: the early units that touch key 700's tile fall back
+    (2, 64, 2048, 2048, 128, True, 2047),    # ... a key only the late (bf16-weights) units ever load: nothing to fall back from
+    (4, 40, 512, 900, 128, False, 100),      # no mask, seqLenK < FA_EARLY_KEYS: every unit runs the fp16-weights kernel and every row sees the key
+    (1, 3, 600, 600, 64, True, 300),         # the pair kernel (small problem), d = 64
+    (2, 96, 1024, 1024, 64, True, 1023),     # d = 64 persistent, all rows early; only the last row sees the key, 63 rows share its tile masked
+])
+def test_default_call_is_finite_and_right_for_any_finite_bf16_v(B, H, S, Sk, d, causal, k_big):
+    """The reference's V is `const float*` (kernels/FlashAttention.cuh:60): any finite value is valid input.  The default call's
+    fp16-weights kernels hold V as fp16, where a finite bf16 |v| > 65504 is inf -- and 0 * inf = NaN would poison rows that do not even
+    see the key (a causally masked key in the row's own tile).  A unit whose fp16 passes come out non-finite is repeated with bf16
+    weights and bf16 V (kernel_bf16.hip.h: run_units): V[k_big] = 1e5 (masked for some rows of its tile under the mask, visible to
+    others) must give a finite O inside the bf16-weights tolerance everywhere, and inside the stated one on the units that never load it."""
+    Q, K, V = randn((B, H, S, d), 701, torch.bfloat16), randn((B, H, Sk, d), 702, torch.bfloat16), randn((B, H, Sk, d), 703, torch.bfloat16)
+    V[:, :, k_big] = 1.0e5
+    V[:, 0, k_big] = -1.0e28                              # (head 0: the largest magnitude the header promises, 2^95 ~ 4e28)
+    Qf, Kf, Vf = (t.float().numpy() for t in (Q, K, V))
+    ref = oracle.attention_numpy(Qf, Kf, Vf, causal=causal)
+    O, lse = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, out_dtype=torch.float32, return_lse=True)
+    O1 = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    for got in (O.cpu().numpy(), O1.cpu().numpy()):
+        assert np.isfinite(got).all()
+        # rows that see the key: |O| is the key's magnitude times its weight, the relative term rules; elsewhere the absolute one (bf16 weights)
+        err = np.abs(got - ref)
+        bad = err > 4e-3 + 4e-3 * np.abs(ref)
+        assert not bad.any(), f"{bad.sum()} / {bad.size} outside 4e-3 + 4e-3|ref|, worst {err[bad].max():.3e}"
+        if causal:          # rows in 256-row blocks entirely in front of the key's tile never load it: the default precision's promise holds
+            clean = (k_big // 64 * 64) // 256 * 256
+            if clean > 0:
+                rep = _parity_table(f"|V|=1e5 at key {k_big}: rows < {clean}", got[:, :, :clean], ref[:, :, :clean])
+                assert rep["pass_frac_at_1e-3"] == 1.0, rep
+    np.testing.assert_allclose(lse.cpu().numpy(), oracle.lse_numpy(Qf, Kf, causal=causal), rtol=2e-5, atol=2e-3)   # (the LSE never sees V)
+
+
+def test_v_of_magnitude_1e5_everywhere():
+    """V ~ 1e5 * N(0,1) on a causal S = 2048 problem: every fp16-weights unit overflows and is repeated with bf16 weights; the result is
+    finite and inside the bf16-weights tolerance at V's scale.  FA_FLAG_F16_WEIGHTS on the same data goes the same way."""
+    B, H, S, d = 1, 160, 2048, 128
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in (711, 712, 713))
+    V = (V.float() * 1.0e5).to(torch.bfloat16)
+    ref = oracle.attention(Q.float().numpy(), K.float().numpy(), V.float().numpy(), causal=True)
+    for wd in (None, torch.float16, torch.bfloat16):
+        O = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=True, out_dtype=torch.float32, weights_dtype=wd)
+        torch.cuda.synchronize()
+        _rel_check(O.cpu().numpy(), ref, 1.0e5, 4e-3, 4e-3)
+
+
+# (causal, weights) -> floor of the pass fraction at the stated tolerance; MEASURED (profiles/r04_pytest_gpu.log, three whole heads, 1.57 M
+# elements): no mask: default = bf16 weights 0.97914, fp16 1.0; causal: default 0.90906 (fp16 on rows < 1024, bf16 above), bf16 0.88290, fp16 1.0
+SHARP_FLOORS = {(False, "default"): 0.975, (False, "bf16"): 0.975, (False, "fp16"): 1.0,
+                (True, "default"): 0.90, (True, "bf16"): 0.875, (True, "fp16"): 1.0}
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_sharp_softmax_parity_is_what_it_measures(causal):
+    """The stated tolerance is met by the default precision on N(0,1) tensors (tests above); it is a property of the DATA: a sharper
+    softmax (Q, K x 3: scores ~ N(0, 9^2)) puts a row's mass on a handful of keys, whose bf16 rounding errors (2^-9 each) no longer
+    average out over the thousands of keys the row sees.  S = 4096, d = 128, whole heads, fp32 output: the default is held to the
+    fraction it measures (floor below it; include/flash_attention.h quotes it), FA_FLAG_F16_WEIGHTS to every element."""
+    B, H, S, d = 1, 160, 4096, 128
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16) for s in (721, 722, 723))
+    Q, K = (Q.float() * 3).to(torch.bfloat16), (K.float() * 3).to(torch.bfloat16)
+    heads = (0, 79, 159)
+    Qf, Kf, Vf = (t.float().numpy() for t in (Q, K, V))
+    ref = np.stack([oracle.attention_rows(Qf, Kf, Vf, (h, h + 1), (0, S), causal=causal)[0] for h in heads])
+    for wd, name in ((None, "default"), (torch.float16, "fp16"), (torch.bfloat16, "bf16")):
+        O = fa.flash_attention(Q.to(DEV), K.to(DEV), V.to(DEV), is_causal=causal, out_dtype=torch.float32, weights_dtype=wd)
+        torch.cuda.synchronize()
+        got = np.stack([O.cpu().numpy().reshape(B * H, S, d)[h] for h in heads])
+        rep = _parity_table(f"SHARP softmax (Q, K x 3) S=4096 causal={causal} weights={name}", got, ref)
+        assert np.isfinite(got).all()
+        assert (np.abs(got - ref) <= 8e-3 + 8e-3 * np.abs(ref)).all(), rep
+        assert rep["pass_frac_at_1e-3"] >= SHARP_FLOORS.get((causal, name), 0.0), rep
+
+
+def test_small_noncausal_shard_against_the_whole_problem():
+    """A shard small enough for the pair kernel against the unsharded run (persistent kernel), no mask, no LSE request: the pair
+    kernel normalises by the fp32 sum of the unrounded weights, the persistent kernel by the MFMA sum of the rounded ones -- equal to
+    2^-9 relative, NOT bit for bit (include/flash_attention.h says so next to flash_attention_lse); with an LSE request on both sides
+    the two are the same arithmetic."""
+    B, H, S, d = 1, 64, 2048, 128
+    Q, K, V = (randn((B, H, S, d), s, torch.bfloat16).to(DEV) for s in (731, 732, 733))
+    assert fa.plan(B, H, S, d, False, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["threads"] == 512 and fa.plan(1, 8, S, d, False, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["threads"] == 256
+    whole = fa.flash_attention(Q, K, V, out_dtype=torch.float32)
+    part = fa.flash_attention(Q[:, 8:16].contiguous(), K[:, 8:16].contiguous(), V[:, 8:16].contiguous(), out_dtype=torch.float32)
+    whole_l, _ = fa.flash_attention(Q, K, V, out_dtype=torch.float32, return_lse=True)
+    part_l, _ = fa.flash_attention(Q[:, 8:16].contiguous(), K[:, 8:16].contiguous(), V[:, 8:16].contiguous(), out_dtype=torch.float32, return_lse=True)
+    torch.cuda.synchronize()
+    a, b = whole[:, 8:16].cpu().numpy(), part.cpu().numpy()
+    assert np.abs(a - b).max() <= 2.0 ** -9 * np.abs(a).max()
+    assert float((whole_l[:, 8:16] - part_l).abs().max()) <= 1e-6
