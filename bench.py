@@ -103,8 +103,9 @@ def bound_for(workload):
 
 def launched_kernel(fa, B, H, S, d, causal, dtype_code, o_code, flags):
     """Name of the kernel the library launches for this problem, from the plan the library itself reports
-    (flash_attention_plan_ex): 256 threads = the pair kernel; both ranges in one launch (unit_lists 1 or 2) = the dual kernel;
-    else the single persistent kernel.  (profiles/*_kernel_stats_*.csv carry the same names from rocprofv3.)"""
+    (flash_attention_plan_ex): 256 threads = the pair kernel, else the persistent kernel fa::fwd_mfma_kernel -- for a causal bf16
+    problem longer than FA_EARLY_KEYS its mixed-precision instantiation (both ranges of the plan in one launch, unit_lists = 1).
+    (profiles/*_kernel_stats_*.csv carry the same names from rocprofv3; round 3's two-kernel launch was fa::fwd_mfma_dual_kernel.)"""
     early, main = fa.plan_ex(B, H, S, S, d, causal, dtype_code, o_code, flags)
     live = main if main["q_blocks"] > 0 else early
     if live["kernel_id"] == 3:
@@ -113,8 +114,6 @@ def launched_kernel(fa, B, H, S, d, causal, dtype_code, o_code, flags):
         return "fa::fwd_generic_kernel"
     if live["threads"] == 256:
         return "fa::fwd_mfma_pair_kernel"
-    if early["q_blocks"] > 0 and main["q_blocks"] > 0 and live["unit_lists"] in (1, 2):
-        return "fa::fwd_mfma_dual_kernel"
     return "fa::fwd_mfma_kernel"
 
 
@@ -307,8 +306,12 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
     traffic, prov = measured_traffic(workload) if world == 1 and default_call else (None, None)
     algo_bytes = heads_local * S * d * (3 * esz + osz)
     flags = {"default": 0, "bf16": fa.FA_FLAG_BF16_WEIGHTS, "f16": fa.FA_FLAG_F16_WEIGHTS}[args.weights] if esz == 2 else 0
-    kernel = launched_kernel(fa, heads_local, 1, S, d, causal, fa.FA_DTYPE_FP8_E4M3 if esz == 1 else fa.FA_DTYPE_BF16,
-                             fa.FA_DTYPE_BF16 if out_dtype == "bf16" else fa.FA_DTYPE_F32, flags)
+    dcode, ocode = (fa.FA_DTYPE_FP8_E4M3 if esz == 1 else fa.FA_DTYPE_BF16), (fa.FA_DTYPE_BF16 if out_dtype == "bf16" else fa.FA_DTYPE_F32)
+    kernel = launched_kernel(fa, heads_local, 1, S, d, causal, dcode, ocode, flags)
+    pe, pm = fa.plan_ex(heads_local, 1, S, S, d, causal, dcode, ocode, flags)
+    kernel_variant = ("mixed precision in one walk: fp16 weights on query blocks [0, %d), bf16 on [%d, %d)" % (pe["q_blocks"], pe["q_blocks"], pe["q_blocks"] + pm["q_blocks"])
+                      if pe["q_blocks"] and pm["q_blocks"] and pm["unit_lists"] == 1 and pm["threads"] == 512
+                      else ("fp16 weights" if pe["q_blocks"] else "one weight precision (bf16)") + (", 128-row units (pair kernel)" if (pm if pm["q_blocks"] else pe)["threads"] == 256 else ""))
     rec = {
         "metric": METRIC if workload.startswith("cfg2") else f"fwd attention TFLOP/s/GPU ({desc}) + % MFMA peak",
         "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": steps,
@@ -316,6 +319,7 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
         "scaling": scaling, "vs_baseline": None, "dtype": "fp8_e4m3fn" if workload == "cfg3" else "bf16",
         "data": "synthetic",
         "config": {"workload": desc, "B": B, "H": H, "S": S, "d": d, "causal": causal,
+                   "kernel_variant": kernel_variant,
                    "out_dtype": out_dtype, "heads_per_gpu": heads_local,
                    "softmax_weights": ({"default": "library default: fp16 on the query rows that see fewer than 1024 keys, bf16 elsewhere",
                                         "bf16": "FA_FLAG_BF16_WEIGHTS: bf16 on every row", "f16": "FA_FLAG_F16_WEIGHTS: fp16 on every row"}[args.weights]

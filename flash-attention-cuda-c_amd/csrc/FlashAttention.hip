@@ -10,7 +10,6 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
-#include <vector>
 
 #include "../../include/flash_attention.h"
 #include "../helpers.hpp"
@@ -98,51 +97,6 @@ static int early_q_blocks(int S, int Sk, int d, bool causal, unsigned flags, int
     if (flags & FA_FLAG_F16_WEIGHTS) return nQ;
     if (Sk < FA_EARLY_KEYS) return nQ;
     return causal ? std::min(nQ, FA_EARLY_KEYS / q_block_rows) : 0;
-}
-
-// The snake schedule (kernel_bf16.hip.h: work_unit) gives every workgroup of an XCD group the same total when the list tiles its
-// rounds; when it does not, the slowest workgroup sets the launch's time.  Cost of one XCD group's walk over a causal list of `heads`
-// heads x nq query blocks starting at block qb0, in tile steps (+4 per unit for its prologue / epilogue): max over workgroups / mean.
-static double snake_imbalance(int64_t heads, int nq, int qb0, int S, int Sk, int qrows, int jpx_max) {
-    const int64_t units = heads * nq, cpx = (units + 7) / 8;
-    if (cpx > (1 << 16)) return 2.0;                       // (not worth a host-side walk: treated as unbalanced)
-    const int jpx = (int)std::min<int64_t>(cpx, jpx_max);
-    std::vector<double> tot(jpx, 0.0);
-    const int k_tiles = (Sk + 63) / 64;
-    for (int64_t idx = 0; idx < cpx && idx < units; ++idx) {
-        const int round = (int)(idx / jpx);
-        int j = (int)(idx % jpx);
-        if (round & 1) j = jpx - 1 - j;
-        const int qb = qb0 + nq - 1 - (int)(idx % nq);     // heaviest first
-        const int q_end = std::min(S, (qb + 1) * qrows);
-        tot[j] += std::min(k_tiles, (q_end + 63) / 64) + 4;
-    }
-    double mx = 0, sum = 0;
-    for (double t : tot) { mx = std::max(mx, t); sum += t; }
-    return sum > 0 ? mx * jpx / sum : 1.0;
-}
-// Causal default precision: walk two lists of their own (late blocks, early blocks) or the single kernel's list twice?  Two lists are
-// the faster form where the late list's schedule is balanced (fwd_mfma_dual_kernel).
-static bool two_lists_are_balanced(int64_t heads, int nQ_total, int hp, int S, int Sk, int qrows, int jpx_max) {
-    // (the walk is up to 64 Ki steps: a caller pays for it once per shape and thread -- a small per-thread LRU, so that a caller
-    //  that alternates a few causal shapes, prefill chunks of several lengths say, does not walk on every launch)
-    struct Memo { int64_t heads; int nQ, hp, S, Sk, qrows, jpx; bool ok; uint64_t used; };
-    constexpr int WAYS = 16;
-    static thread_local Memo memo[WAYS] = {};
-    static thread_local uint64_t tick = 0;
-    ++tick;
-    int victim = 0;
-    for (int i = 0; i < WAYS; ++i) {
-        Memo& m = memo[i];
-        if (m.used && m.heads == heads && m.nQ == nQ_total && m.hp == hp && m.S == S && m.Sk == Sk && m.qrows == qrows && m.jpx == jpx_max) {
-            m.used = tick;
-            return m.ok;
-        }
-        if (m.used < memo[victim].used) victim = i;   // (an empty way has used == 0: taken first)
-    }
-    const bool ok = snake_imbalance(heads, nQ_total - hp, hp, S, Sk, qrows, jpx_max) <= 1.02;
-    memo[victim] = Memo{heads, nQ_total, hp, S, Sk, qrows, jpx_max, ok, tick};
-    return ok;
 }
 
 // Small problems take the pair kernel (kernel_bf16.hip.h: fwd_mfma_pair_kernel): 128-row units, one per workgroup of four waves.
@@ -267,6 +221,7 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
     const int nQ_total = getNumCta(S, plan.q_block_rows);
     if ((int64_t)B * H * nQ_total > INT32_MAX / 2) return FA_ERR_BAD_SHAPE;   // unit indices are 32-bit
     p.dbg = nullptr;
+    p.hp = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // One launch covers the query blocks [qb0, qb0 + nq) of every head.
     auto set_range = [&](int qb0, int nq, bool persistent) {
@@ -288,9 +243,9 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
     } else if (plan.kernel_id == 1) {   // bf16 inputs
         // Which query blocks take fp16 softmax weights (early_q_blocks): all with FA_FLAG_F16_WEIGHTS, none with
         // FA_FLAG_BF16_WEIGHTS, by default the rows that see few keys.  Both kinds present (a causal problem longer than
-        // FA_EARLY_KEYS): ONE launch; every workgroup runs its late units with the bf16-weights kernel, then its early units with
-        // the fp16-weights kernel (disjoint output rows) -- from two unit lists of their own where that schedule is balanced (the
-        // faster form), else from the single kernel's list (kernel_bf16.hip.h: fwd_mfma_dual_kernel).
+        // FA_EARLY_KEYS): ONE launch of ONE kernel over the list of all query blocks, in the single kernel's head-aligned order (all of a
+        // head's blocks start in one round of one XCD group, so its K/V is streamed from that XCD's L2); every unit runs in the
+        // precision of its block (kernel_bf16.hip.h: KernelCfg::MIX).
         const int hp = early_q_blocks(S, Sk, d, causal, flags, plan.q_block_rows);
         if (pair_kernel_applies(B, H, S, d, causal, dtype, scale)) {   // (make_plan chose 128-row blocks, 256 threads, its grid)
             p.qb0 = 0;
@@ -300,17 +255,9 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
             p.jpx = device_cus() / 8;   // (workgroups of one dispatch round per XCD group: what the pairing counts in)
             e = d == 64 ? launch_bf16_pair_d64(p, hp, p.jpx, plan, causal, o_dtype, st) : launch_bf16_pair_d128(p, hp, p.jpx, plan, causal, o_dtype, st);
         } else if (hp > 0 && hp < nQ_total && causal) {   // (without the mask early_q_blocks is all or nothing)
-            if (two_lists_are_balanced(B * H, nQ_total, hp, S, Sk, plan.q_block_rows, device_cus() / 8)) {
-                set_range(hp, nQ_total - hp, true);
-                const UnitList late = unit_list_of(p);
-                const int grid_late = plan.grid;
-                set_range(0, hp, true);
-                plan.grid = std::max(plan.grid, grid_late);
-                e = launch_bf16_causal_dual(p, late, unit_list_of(p), hp, plan, d, o_dtype, st);
-            } else {
-                set_range(0, nQ_total, true);
-                e = launch_bf16_causal_dual(p, unit_list_of(p), unit_list_of(p), hp, plan, d, o_dtype, st);
-            }
+            set_range(0, nQ_total, true);
+            p.hp = hp;
+            e = launch_bf16_causal_mix(p, plan, d, o_dtype, st);
         } else if (hp > 0) {
             set_range(0, hp, true);
             e = launch_bf16_p16(p, plan, causal, d, o_dtype, st);
@@ -474,13 +421,12 @@ int flash_attention_plan_ex(int batchSize, int numHeads, int seqLenQ, int seqLen
     if (base.kernel_id == 1 && base.threads == 256) {   // the pair kernel: one launch whatever the ranges, its own grid and LDS size
         if (early && hp > 0) early->launch = base;
         if (main_ && nQ - hp > 0) main_->launch = base;
-    } else if (hp > 0 && hp < nQ) {   // both kinds: one launch (fwd_mfma_dual_kernel) with the larger LDS carve-up; the grid of its longest list
-        const bool two = fa::two_lists_are_balanced((int64_t)batchSize * numHeads, nQ, hp, seqLenQ, seqLenK, base.q_block_rows, fa::device_cus() / 8);
-        const int64_t units = (int64_t)batchSize * numHeads * (two ? std::max(hp, nQ - hp) : nQ);
+    } else if (hp > 0 && hp < nQ) {   // both kinds: ONE launch of the mixed-precision kernel over the list of all query blocks
+        const int64_t units = (int64_t)batchSize * numHeads * nQ;
         const int grid = (int)(8 * std::min<int64_t>((units + 7) / 8, fa::device_cus() / 8));
-        const int lds = fa::bf16_causal_dual_lds_bytes(dHead, o_dtype);
-        if (early) { early->launch.grid = grid; early->launch.lds_bytes = lds; early->unit_lists = two ? 2 : 1; }
-        if (main_) { main_->launch.grid = grid; main_->launch.lds_bytes = lds; main_->unit_lists = two ? 2 : 1; }
+        const int lds = fa::bf16_causal_mix_lds_bytes(dHead, o_dtype);
+        if (early) { early->launch.grid = grid; early->launch.lds_bytes = lds; early->unit_lists = 1; }
+        if (main_) { main_->launch.grid = grid; main_->launch.lds_bytes = lds; main_->unit_lists = 1; }
     }
     return FA_OK;
 }

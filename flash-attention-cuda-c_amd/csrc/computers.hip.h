@@ -60,8 +60,9 @@ struct WaveCompute {
     static constexpr int NE = 32 * R;              // score elements per lane per tile
     static constexpr int SPAN = SA + (3 * SB) / 4; // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
-    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, false, true>,
-                                     std::conditional_t<C::DMA_K8, HybridStageFp8<D, C::NWAVES>, BufStage<D, ESZ, C::NWAVES, C::PAD>>>;
+    using Stage = std::conditional_t<C::MIX, MixStage<D, C::NWAVES>,
+                  std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, false, true>,
+                                     std::conditional_t<C::DMA_K8, HybridStageFp8<D, C::NWAVES>, BufStage<D, ESZ, C::NWAVES, C::PAD>>>>;
     using ScoresT = Scores<R>;
     static constexpr int NL = Stage::NL, NW = Stage::NW;
     static constexpr int WSTEP = 2 * NW <= SB / 2 + 1 ? 2 : 1;   // LDS writes sit in every WSTEP-th slot of the second half of phase B
@@ -85,11 +86,16 @@ struct WaveCompute {
     // (Later is worse -- the pieces then land after the end-of-step wait: phase A's second half -2.6 %, phase B -9 ... -13 %,
     //  profiles/r03_tune_c_dma_slots_*.log.)
     __host__ __device__ static constexpr int load_slot(int n) { return 1 + 2 * n; }
-    template <int SLOT, int N = 0>
+    // F16W (mixed-precision kernels, C::MIX, only): the unit runs with fp16 softmax weights -- P rounded to fp16, V staged as fp16 through
+    // registers (MixStage), P.V on v_mfma_f32_32x32x16_f16.  A property of the pass, handed down as a template argument.
+    template <int SLOT, bool F16W = false, int N = 0>
     __device__ __forceinline__ void load_in_slot(Stage& st, int t_load) {
         if constexpr (N < NL) {
-            if constexpr (load_slot(N) == SLOT) st.template load<N>(t_load);
-            load_in_slot<SLOT, N + 1>(st, t_load);
+            if constexpr (load_slot(N) == SLOT) {
+                if constexpr (C::MIX) st.template load<N, F16W>(t_load);
+                else st.template load<N>(t_load);
+            }
+            load_in_slot<SLOT, F16W, N + 1>(st, t_load);
         }
     }
 
@@ -246,25 +252,25 @@ struct WaveCompute {
 
     // ---- softmax slices ------------------------------------------------------------------------
     // Element E (0..32R-1) = (key group g = E/(8R), row group r = (E/8)%R, j = E%8) -> score 8g+j of row group r.
-    template <int E>
+    template <int E, bool F16W = false>
     __device__ __forceinline__ void exp_elem(const Scores<R>& cur, float c) {
         constexpr int g = E / (8 * R), r = (E / 8) % R, j = E % 8, e = 8 * g + j;
         const float x = cur.s[r][e >> 4][e & 15];
         const float p = fast_exp2(fmaf(x, c, -m[r]));
         if constexpr (e & 1) {
             sum_b[r] += p;
-            pw[r][e >> 1] = pack_bf16(p_even, p);
+            pw[r][e >> 1] = F16W ? pack_f16(p_even, p) : pack_bf16(p_even, p);
             asm volatile("" : "+v"(sum_a[r]), "+v"(sum_b[r]));   // keep the adds in this slot (hipcc sinks them)
         } else {
             sum_a[r] += p;
             p_even = p;
         }
     }
-    template <int SLOT, int E = 0>
+    template <int SLOT, bool F16W = false, int E = 0>
     __device__ __forceinline__ void exp_slot(const Scores<R>& cur, float c) {
         if constexpr (E < NE) {
-            if constexpr (elem_slot(E) == SLOT) exp_elem<E>(cur, c);
-            exp_slot<SLOT, E + 1>(cur, c);
+            if constexpr (elem_slot(E) == SLOT) exp_elem<E, F16W>(cur, c);
+            exp_slot<SLOT, F16W, E + 1>(cur, c);
         }
     }
     __device__ __forceinline__ bf16x8 p_frag(int r, int g) const {
@@ -308,12 +314,12 @@ struct WaveCompute {
 
     // ---- the slots -----------------------------------------------------------------------------
     // phase A slot I: fragment f = I/(MPF*R), then (sub, row group) = ((I % (MPF*R)) / R, I % R)
-    template <int I, bool DMA_A = true>
+    template <int I, bool DMA_A = true, bool F16W = false>
     __device__ __forceinline__ void slots_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase,
                                             float c, const Scores<R>& cur, Scores<R>& nxt) {
         if constexpr (I < SA) {
             constexpr int f = I / (MPF * R), rem = I % (MPF * R), sub = rem / R, rg = rem % R;
-            if constexpr (C::VALU_FIRST) exp_slot<I>(cur, c);   // softmax slice covers the fragment's LDS latency
+            if constexpr (C::VALU_FIRST) exp_slot<I, F16W>(cur, c);   // softmax slice covers the fragment's LDS latency
             qk_mfma<f, sub, rg>(kf[(f + NPRE - 1) % NPRE], kf[f % NPRE], nxt);
             if constexpr (C::MXQK) {
                 // both fragments of a pair stay live until the pair's MFMA: refill the two window entries after it
@@ -328,31 +334,34 @@ struct WaveCompute {
                 constexpr int v = I - (SA - VPRE);
                 vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DB, v % DB);
             }
-            if constexpr (DMA_A) load_in_slot<I>(st, t_load);
-            if constexpr (!C::VALU_FIRST) exp_slot<I>(cur, c);
+            if constexpr (DMA_A) load_in_slot<I, F16W>(st, t_load);
+            if constexpr (!C::VALU_FIRST) exp_slot<I, F16W>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
-            slots_a<I + 1, DMA_A>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+            slots_a<I + 1, DMA_A, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         }
     }
     // phase B slot J: V^T fragment v = J/R (16-key step v/DB, d block v%DB), row group J%R
-    template <bool TRACK, int J, bool DMA_B = false>
+    template <bool TRACK, int J, bool DMA_B = false, bool F16W = false>
     __device__ __forceinline__ void slots_b(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
                                             const Scores<R>& cur, const Scores<R>& nxt) {
         if constexpr (J < SB) {
             constexpr int v = J / R, rg = J % R, s4 = v / DB, db = v % DB;
-            o[rg][db] = mfma_32x32x16(vf[v % (VPRE + 1)], p_frag(rg, s4), o[rg][db]);
+            if constexpr (F16W) o[rg][db] = mfma_32x32x16(__builtin_bit_cast(f16x8, vf[v % (VPRE + 1)]), __builtin_bit_cast(f16x8, p_frag(rg, s4)), o[rg][db]);
+            else o[rg][db] = mfma_32x32x16(vf[v % (VPRE + 1)], p_frag(rg, s4), o[rg][db]);
             if constexpr (rg == R - 1 && v + VPRE < NB) {
                 constexpr int vn = v + VPRE;
                 vf[vn % (VPRE + 1)] = v_frag(v_cur, vbase, vn / DB, vn % DB);
             }
-            if constexpr (DMA_B) load_in_slot<J>(st, t_load);
-            exp_slot<SA + J>(cur, c);
+            if constexpr (DMA_B) load_in_slot<J, F16W>(st, t_load);
+            exp_slot<SA + J, F16W>(cur, c);
             if constexpr (TRACK && J < SB / 2) max3_slot<J>(nxt);
             if constexpr (TRACK && J == SB / 2) decide(c);
-            if constexpr (J >= SB / 2 && (J - SB / 2) % WSTEP == 0 && (J - SB / 2) / WSTEP < NW)
-                st.template write<(J - SB / 2) / WSTEP>(wr_slot);
+            if constexpr (J >= SB / 2 && (J - SB / 2) % WSTEP == 0 && (J - SB / 2) / WSTEP < NW) {
+                if constexpr (C::MIX) st.template write<(J - SB / 2) / WSTEP, F16W>(wr_slot);
+                else st.template write<(J - SB / 2) / WSTEP>(wr_slot);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            slots_b<TRACK, J + 1, DMA_B>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt);
+            slots_b<TRACK, J + 1, DMA_B, F16W>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt);
         }
     }
 
@@ -363,7 +372,7 @@ struct WaveCompute {
     // The step comes in two halves so that the staggered kernels (KernelCfg::STAG) can put the workgroup barrier between them
     // for half of the waves: tile_a = phase A, tile_b = phase B + the end-of-tile work.  DMA_A / DMA_B: which half issues the
     // wave's LDS-DMA pieces of tile t_load (the caller has set their destination: Stage::set_dst / set_dst2).
-    template <bool DMA_A = true>
+    template <bool DMA_A = true, bool F16W = false>
     __device__ __forceinline__ void tile_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase, float c,
                                            const Scores<R>& cur, Scores<R>& nxt) {
 #pragma unroll
@@ -376,18 +385,18 @@ struct WaveCompute {
         for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
         if constexpr (C::PRIO_A) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
-        slots_a<0, DMA_A>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        slots_a<0, DMA_A, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         if constexpr (C::PRIO_A) {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (C::STAMP) t_mid = cycle_stamp();
     }
-    template <bool TRACK, bool DMA_B = false>
+    template <bool TRACK, bool DMA_B = false, bool F16W = false>
     __device__ __forceinline__ void tile_b(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
                                            const Scores<R>& cur, Scores<R>& nxt,
                                            bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
-        slots_b<TRACK, 0, DMA_B>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt);
+        slots_b<TRACK, 0, DMA_B, F16W>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
 #pragma unroll
         for (int r = 0; r < R; ++r) l[r] += sum_a[r] + sum_b[r];
@@ -418,13 +427,13 @@ struct WaveCompute {
             }
         }
     }
-    template <bool TRACK>
+    template <bool TRACK, bool F16W = false>
     __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
                                               int kbase, int vbase, float c, const Scores<R>& cur, Scores<R>& nxt,
                                               bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
         st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
-        tile_a<true>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
-        tile_b<TRACK, false>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt, has_next, mask_next, kv0_next, q_row0, S, lane);
+        tile_a<true, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        tile_b<TRACK, false, F16W>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt, has_next, mask_next, kv0_next, q_row0, S, lane);
     }
 
     // True iff a row sum or any O accumulator of this lane is inf / NaN (x*0 is NaN for both).  Four independent

@@ -44,6 +44,8 @@ struct Opt {
                                  // problems with one 256-row unit per CU or fewer (fwd_mfma_pair_kernel)
     bool p_f16 = false;          // 16x16x32 engine: weights rounded to fp16 (11 significant bits) instead of bf16 (8), V staged as fp16, P.V
                                  // on v_mfma_f32_16x16x32_f16 (needs |V| <= 65504): FA_FLAG_F16_WEIGHTS, and by default the query blocks whose rows see few keys
+    bool mix = false;            // 32x32x16 engine, LDS-DMA kernels: the units of the query blocks qb < Params::hp run with fp16 softmax weights (V staged
+                                 // as fp16 through registers: MixStage), the others with bf16 weights, in list order inside ONE walk: the causal default
     int prio_a = -1;             // phase A of a tile step at s_setprio 1 (-1: on)
     int stag = 0;                // half-step stagger of the two waves of a SIMD (LDS-DMA kernels, 8 waves): 1 = waves 4-7 run half a tile step
                                  // behind waves 0-3 (their workgroup barrier sits between phase A and phase B), 2 = waves 0-3 behind waves 4-7.
@@ -82,6 +84,10 @@ struct KernelCfg {
     // the load and the LDS write and keep the register path.  The epilogue's LDS regions sit behind ring slot 0: the next
     // unit's tile 0 lands there while the epilogue runs
     static constexpr bool DMA = ESZ_ == 2 && !O.pad && !O.p_f16;
+    // both weight precisions in one kernel, chosen per unit (run_units); the K/V ring, the K image, the engine and the epilogue are
+    // those of the LDS-DMA kernel, only V's way into LDS and the P.V operand type differ per unit
+    static constexpr bool MIX = O.mix && DMA && !M16;
+    static_assert(!O.mix || (ESZ_ == 2 && !O.pad && !O.p_f16 && O.m16 == 0), "the mixed-precision kernel is the 32x32x16 LDS-DMA kernel");
     // fp8 inputs: K alone by LDS-DMA (V is widened to bf16 on its way into LDS and keeps the register path): HybridStageFp8
     static constexpr bool DMA_K8 = ESZ_ == 1 && D_ == 128 && !O.pad && O.waves == 8;
     static constexpr int NPRE = 4;                   // K fragments in flight ahead of their MFMA
@@ -138,6 +144,11 @@ __device__ __forceinline__ bool block_or(bool v, lds_ptr flags, int wave) {
     return __builtin_amdgcn_readfirstlane(r) != 0;
 }
 
+// The causal default: the bf16-weights kernel whose units of the query blocks qb < Params::hp (the rows that see fewer than FA_EARLY_KEYS
+// keys) run with fp16 weights -- ONE walk over ONE (head, query block) list, every unit in the precision of its block
+template <int D, typename OutT, bool STAMP = false>
+using MixCfg = KernelCfg<D, true, OutT, 2, Opt{.stamp = STAMP, .m16 = 0, .mix = true}>;
+
 // The per-wave compute engine of a configuration: 16x16x32 MFMAs (computers16.hip.h) or 32x32x16 (computers.hip.h).
 template <class C>
 using WaveComputeOf = std::conditional_t<C::M16, WaveCompute16<C>, WaveCompute<C>>;
@@ -167,15 +178,22 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
 
     // Prologue: tile 0 (requested by the caller together with Q on the first pass) -> LDS, barrier; then
     // tile 1 is fetched while S(0) = K(0).Q^T and its row max are computed.
-    if (!tile0_in_flight) st.load_all_into(0, smem);
-    if constexpr (C::P_F16) st.template write_all<0, F16W>(smem);
-    else st.write_all(smem);
+    // (MIX / P_F16: the form of the tile -- V as fp16 through registers or as bf16 -- follows the pass)
+    if constexpr (C::MIX) {
+        if (!tile0_in_flight) st.template load_all_into<F16W>(0, smem);
+        st.template write_all<F16W>(smem);
+    } else {
+        if (!tile0_in_flight) st.load_all_into(0, smem);
+        if constexpr (C::P_F16) st.template write_all<0, F16W>(smem);
+        else st.write_all(smem);
+    }
     unsigned long long tw0 = 0;
     if constexpr (C::STAMP) tw0 = cycle_stamp();
     st.wait_all();
     if constexpr (C::STAMP) acc[16] += cycle_stamp() - tw0;   // (vmcnt(0): tile 0's pieces AND the previous unit's output stores)
     __syncthreads();
-    st.load_all_into(1, smem + SLOT);          // past-the-end tiles read as zeros (buffer range check)
+    if constexpr (C::MIX) st.template load_all_into<F16W>(1, smem + SLOT);
+    else st.load_all_into(1, smem + SLOT);     // past-the-end tiles read as zeros (buffer range check)
     constexpr int AHEAD = C::RING - 1;                 // iteration t stages tile t + AHEAD
     if constexpr (C::STAMP) tp1 = cycle_stamp();
     if (my_tiles > 0) {
@@ -183,7 +201,8 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
         if (needs_mask(0)) w.mask(sA, 0, q_row0, S, lane);
         w.first_max(sA, c);   // m = row max of tile 0 (the reference of the optimistic pass)
     }
-    if constexpr (C::P_F16) st.template write_all<0, F16W>(smem + SLOT);
+    if constexpr (C::MIX) st.template write_all<F16W>(smem + SLOT);
+    else if constexpr (C::P_F16) st.template write_all<0, F16W>(smem + SLOT);
     else st.write_all(smem + SLOT);
     st.wait_all();
     __syncthreads();
@@ -198,16 +217,21 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
         if constexpr (C::STAMP) t0 = cycle_stamp();
         if (kind != 2) {
             const bool has_next = kind == 0;
-            if constexpr (C::P_F16)
+            if constexpr (C::P_F16 || C::MIX)
                 w.template tile_step<TRACK, F16W>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
                                                   has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
             else
                 w.template tile_step<TRACK>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
                                             has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
         } else {
-            st.load_all_into(t + AHEAD, smem + so_wr);
-            if constexpr (C::P_F16) st.template write_all<0, F16W>(smem + so_wr);
-            else st.write_all(smem + so_wr);
+            if constexpr (C::MIX) {
+                st.template load_all_into<F16W>(t + AHEAD, smem + so_wr);
+                st.template write_all<F16W>(smem + so_wr);
+            } else {
+                st.load_all_into(t + AHEAD, smem + so_wr);
+                if constexpr (C::P_F16) st.template write_all<0, F16W>(smem + so_wr);
+                else st.write_all(smem + so_wr);
+            }
         }
         if constexpr (C::STAMP) t4 = cycle_stamp();
         st.wait_all();   // (LDS-DMA staging: this wave's pieces of tile t + AHEAD have landed)
@@ -227,7 +251,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
         step(t, kind_of(t), sA, sB);
         if (t + 1 < n_tiles) step(t + 1, kind_of(t + 1), sB, sA);
     }
-    if constexpr (TRACK && !(C::P_F16 && F16W)) return false;
+    if constexpr (TRACK && !F16W) return false;
     else {
         unsigned long long tc0 = 0;
         if constexpr (C::STAMP) tc0 = cycle_stamp();
@@ -373,7 +397,9 @@ struct UnitCtx {
     float* lse_head;
     int q_row0, n_tiles, my_tiles;
     bool wave_live;
+    bool early;   // C::MIX: this unit runs with fp16 softmax weights (query block qb < Params::hp)
     __device__ __forceinline__ void set(const Params& p, int g, int qb, int wave) {
+        early = C::MIX && qb < p.hp;
         constexpr int ESZ = C::ESZ, KVBLK = 64, QBLK = C::QBLK, WROWS = 32;
         const int b = g / p.H, h = g - b * p.H;
         Qh = (const char*)p.Q + (b * p.qB + h * p.qH) * ESZ;
@@ -391,33 +417,27 @@ struct UnitCtx {
     }
 };
 
-// Which units of its list a walk takes: all of them (the single kernels), or -- in the launch that mixes two configurations
-// (fwd_mfma_dual_kernel) -- only the units of the query blocks qb >= hp (LATE) / qb < hp (EARLY).
-enum class Kind { ALL, LATE, EARLY, ONE };   // ONE: the single unit (head L.units, query block L.qb0) -- fwd_mfma_pair_kernel
+// Which units a walk takes: all of its list (the persistent kernels), or the single unit (head L.units, query block L.qb0) of a
+// workgroup of fwd_mfma_pair_kernel.
+enum class Kind { ALL, ONE };
 template <class C, Kind KIND>
-__device__ __forceinline__ bool next_unit(const UnitList& L, int& round, int& g, int& qb, int hp) {
+__device__ __forceinline__ bool next_unit(const UnitList& L, int& round, int& g, int& qb) {
     if constexpr (KIND == Kind::ALL) return work_unit<C>(L, round, g, qb);
-    else if constexpr (KIND == Kind::ONE) {
+    else {
         g = L.units;
         qb = L.qb0;
         return round == 0;
-    } else {
-        while (work_unit<C>(L, round, g, qb)) {
-            if ((qb < hp) == (KIND == Kind::EARLY)) return true;
-            ++round;
-        }
-        return false;
     }
 }
 
-// Everything a workgroup does with configuration C: walk the units of list L that are of its kind.
+// Everything a workgroup does with configuration C: walk its units of list L.
 template <class C, Kind KIND = Kind::ALL>
-__device__ __forceinline__ void run_units(const Params& p, const UnitList& L, lds_ptr smem, int hp = 0) {
+__device__ __forceinline__ void run_units(const Params& p, const UnitList& L, lds_ptr smem) {
     constexpr int D = C::D, ESZ = C::ESZ;
     using OutT = typename C::OutT;
 
     int g, qb, round = 0;
-    if (!next_unit<C, KIND>(L, round, g, qb, hp)) return;
+    if (!next_unit<C, KIND>(L, round, g, qb)) return;
     unsigned long long t_kernel0 = 0, t_real0 = 0;
     if constexpr (C::STAMP) { t_real0 = realtime_stamp(); t_kernel0 = cycle_stamp(); }
     const int lane = threadIdx.x & 63;
@@ -432,7 +452,13 @@ __device__ __forceinline__ void run_units(const Params& p, const UnitList& L, ld
     typename WaveComputeOf<C>::Stage st;
     const int row_bytes = C::PAD ? p.d * ESZ : D * ESZ, orow_bytes = C::PAD ? p.d * (int)sizeof(OutT) : D * (int)sizeof(OutT);
     st.init(cur.Kh, cur.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
-    st.load_all_into(0, smem);                      // tile 0 and Q travel together (one HBM round trip)
+    // tile 0 and Q travel together (one HBM round trip); C::MIX: in the form the unit's pass takes it (wave-uniform branch)
+    if constexpr (C::MIX) {
+        if (cur.early) st.template load_all_into<true>(0, smem);
+        else st.template load_all_into<false>(0, smem);
+    } else {
+        st.load_all_into(0, smem);
+    }
     if constexpr (C::COALESCED_Q) w.load_q_rows(cur.Qh, qSb, cur.q_row0, S, lane);
     else w.load_q(cur.Qh, qSb, cur.q_row0, S, lane, row_bytes);
     unsigned long long acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -469,6 +495,17 @@ __device__ __forceinline__ void run_units(const Params& p, const UnitList& L, ld
                 if (lag) attention_pass_stag<C, true, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false);
                 else attention_pass_stag<C, true, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false);
             }
+        } else if constexpr (C::MIX) {
+            // both precisions in one walk: the unit's query block says which.  An fp16 unit whose passes come out non-finite (V beyond
+            // fp16's range, see below) is repeated by the bf16-weights tracked pass -- the one a bf16 unit falls back to anyway
+            if (cur.early) {
+                if (attention_pass<C, false, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true))
+                    if (attention_pass<C, true, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false))
+                        attention_pass<C, true, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false);
+            } else {
+                if (attention_pass<C, false, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true))
+                    attention_pass<C, true, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false);
+            }
         } else if constexpr (C::P_F16) {
             // fp16 weights need V in fp16: a finite bf16 |v| > 65504 is inf there (and 0 * inf = NaN poisons rows that do not even see
             // the key).  Both fp16 passes report a non-finite result; the last resort is the bf16-weights tracked pass, which holds
@@ -488,11 +525,16 @@ __device__ __forceinline__ void run_units(const Params& p, const UnitList& L, ld
         if constexpr (C::STAMP) t_nx0 = cycle_stamp();
         UnitCtx<C> nxt;
         ++round;
-        const bool more = next_unit<C, KIND>(L, round, g, qb, hp);
+        const bool more = next_unit<C, KIND>(L, round, g, qb);
         if (more) {
             nxt.set(p, g, qb, wave);
             st.init(nxt.Kh, nxt.Vh, kSb, vSb, Sk, wave, lane, row_bytes);
-            st.load_all_into(0, smem);
+            if constexpr (C::MIX) {
+                if (nxt.early) st.template load_all_into<true>(0, smem);   // (V in registers across the epilogue)
+                else st.template load_all_into<false>(0, smem);
+            } else {
+                st.load_all_into(0, smem);
+            }
             // (opaque lane: a hoisted per-lane Q address is spilled across the tile loop, and its reload's vmcnt(0)
             // would make the Q loads wait for the tile-0 loads just issued)
             int lane_n = lane;
@@ -554,29 +596,6 @@ __global__ __launch_bounds__(64 * C::NWAVES, 2) void fwd_mfma_kernel(const Param
     run_units<C>(p, unit_list_of(p), (lds_ptr)smem_raw);
 }
 
-// Two configurations in ONE launch.  This is how the library's default precision runs a causal bf16 problem: CA = the bf16-weights
-// kernel for the query blocks qb >= hp, CB = the fp16-weights kernel for the hp first blocks of every head (the rows that see fewer
-// than FA_EARLY_KEYS keys).  Every workgroup first runs its late units, then its early units (chained with cross-unit prefetch
-// inside each kind).  Which units are "its": the host picks one of two forms (csrc/FlashAttention.hip, dual_launch_form):
-//   two lists   la = the late blocks of all heads as a list of its own (qb0 = hp, nQ = blocks - hp), lb = the early blocks: each with
-//               its own snake schedule.  As fast as the single kernel when the late list's schedule is balanced (cfg2: 12 blocks per
-//               head, 6 whole rounds: 0.5237 against 0.5251 ms) -- and up to 54 % out of balance when it is not (64 heads at
-//               S = 8192: -10 %);
-//   one list    la = lb = the single kernel's list over all blocks: a workgroup skips the units of the other kind, so its total is
-//               what the single kernel gives it, whatever the shape (S = 8192: -2.9 %); but a workgroup that skips an early
-//               unit starts the next round's heads ahead of the others: -4.6 % at cfg2.
-// Measured alternatives (profiles/r03_tune_e_*, _f_*, _k_*, _n_*, r03_fetch_by_variant.txt): two launches, one per kind: +2.4 % time at
-// cfg2 (a 56 us launch of 512 tiny units, a kernel boundary, two tails); every unit dispatched to its kind in list order: half of
-// the workgroups alternate kinds at every unit boundary and lose the cross-unit prefetch there: -3.8 %.
-template <class CA, class CB>
-__global__ __launch_bounds__(64 * CA::NWAVES, 2) void fwd_mfma_dual_kernel(const Params p, const UnitList la, const UnitList lb, const int hp) {
-    static_assert(CA::NWAVES == CB::NWAVES && CA::CAUSAL == CB::CAUSAL && CA::QBLK == CB::QBLK, "one workgroup shape, one unit list");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    run_units<CA, Kind::LATE>(p, la, (lds_ptr)smem_raw, hp);
-    __syncthreads();   // (the two configurations carve the LDS differently: A's last epilogue regions against B's first ring slots)
-    run_units<CB, Kind::EARLY>(p, lb, (lds_ptr)smem_raw, hp);
-}
-
 // Small causal problems: ONE unit per workgroup, 128 query rows, four waves; two workgroups per CU at d = 64, one at d = 128 (where the
 // launch simply reaches twice the CUs; jpx then covers every unit and nothing below is paired).  With one 256-row unit per CU (or
 // fewer) the launch lasts as long as its heaviest unit while the counted work is the mean -- 4.5 / 8 at BASELINE cfg1.  Here the units
@@ -599,8 +618,8 @@ __global__ __launch_bounds__(64 * CA::NWAVES, 2) void fwd_mfma_pair_kernel(const
     if (idx >= n || (s >= jpx && idx < jpx)) return;
     const int blk = idx / nh;
     const UnitList one{p.nQ, p.nQ - 1 - blk, h0 + (idx - blk * nh), 0, 0};
-    if (one.qb0 < hp) run_units<CB, Kind::ONE>(p, one, (lds_ptr)smem_raw, hp);
-    else run_units<CA, Kind::ONE>(p, one, (lds_ptr)smem_raw, hp);
+    if (one.qb0 < hp) run_units<CB, Kind::ONE>(p, one, (lds_ptr)smem_raw);
+    else run_units<CA, Kind::ONE>(p, one, (lds_ptr)smem_raw);
 }
 
 }  // namespace fa

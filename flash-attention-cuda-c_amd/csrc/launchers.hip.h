@@ -33,17 +33,16 @@ hipError_t launch_bf16_d128(const Params& p, const fa_launch_plan& plan, bool ca
 hipError_t launch_bf16_d64(const Params& p, const fa_launch_plan& plan, bool causal, bool pad, int o_dtype, hipStream_t st);
 // bf16 inputs, fp16-weights precision option (d = 128 or 64 exactly)
 hipError_t launch_bf16_p16(const Params& p, const fa_launch_plan& plan, bool causal, int d, int o_dtype, hipStream_t st);
-// bf16 inputs, causal, default precision, d = 128 or 64 exactly: both kernels in one launch (the hp first query blocks of every head:
-// fp16 weights, unit list lb; the rest: bf16 weights, unit list la)
+// bf16 inputs, causal, default precision, d = 128 or 64 exactly: one kernel, one (head, query block) list; the units of the first p.hp
+// query blocks of every head run with fp16 weights, the rest with bf16 weights (inst_bf16_mix.hip)
+hipError_t launch_bf16_causal_mix(const Params& p, const fa_launch_plan& plan, int d, int o_dtype, hipStream_t st);
+int bf16_causal_mix_lds_bytes(int d, int o_dtype);
 // small problems: 128-row units, one per workgroup of four waves -- causal at D = 64: two workgroups per CU, paired; else one per CU
 // (inst_bf16_pair_d64.hip, inst_bf16_pair_d128.hip)
 hipError_t launch_bf16_pair_d64(const Params& p, int hp, int jpx, const fa_launch_plan& plan, bool causal, int o_dtype, hipStream_t st);
 hipError_t launch_bf16_pair_d128(const Params& p, int hp, int jpx, const fa_launch_plan& plan, bool causal, int o_dtype, hipStream_t st);
 int bf16_pair_d64_lds_bytes(bool causal, int o_dtype);
 int bf16_pair_d128_lds_bytes(bool causal, int o_dtype);
-hipError_t launch_bf16_causal_dual(const Params& p, const UnitList& la, const UnitList& lb, int hp, const fa_launch_plan& plan, int d, int o_dtype,
-                                   hipStream_t st);
-int bf16_causal_dual_lds_bytes(int d, int o_dtype);
 // fp8 e4m3fn inputs (always the D = 128 instantiation)
 hipError_t launch_fp8_d128(const Params& p, const fa_launch_plan& plan, bool causal, bool pad, int o_dtype, hipStream_t st);
 // fp32 inputs, exact-fp32 MFMA kernel

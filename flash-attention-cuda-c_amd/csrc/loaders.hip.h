@@ -46,6 +46,7 @@ struct Params {
     int units;        // B*H*nQ
     int cpx;          // ceil(units / 8): work units per XCD group
     int jpx;          // persistent grid only: workgroups per XCD group (grid / 8)
+    int hp;           // mixed-precision kernels (KernelCfg::MIX): the query blocks qb < hp of every head take fp16 softmax weights
     float scale_log2; // scale * log2(e)
     float scale;
     unsigned long long* dbg;  // diagnostic builds only (tests/fa_tune): per-wave segment cycle sums
@@ -316,6 +317,46 @@ struct DmaStage {
     __device__ __forceinline__ void load_all_into(int t, lds_ptr slot) { set_dst(slot); load_all(t); }
     __device__ __forceinline__ void load_all_into2(int t, lds_ptr kimg, lds_ptr vimg) { set_dst2(kimg, vimg); load_all(t); }
     __device__ __forceinline__ void write_all(lds_ptr) const {}
+};
+
+// ---- bf16 inputs, both weight precisions in one kernel (KernelCfg::MIX: the causal default) ------------------------------------------------
+// K always by LDS-DMA.  V by LDS-DMA for the units that run with bf16 weights; for the units that run with fp16 weights V has to become
+// fp16 on its way (the P.V MFMA then is v_mfma_f32_32x32x16_f16), so it goes through registers as in BufStage: buffer load, convert,
+// ds_write_b128 into the SAME V image.  Which form a tile takes is a template argument of every call (F16W), i.e. a property of the pass the
+// unit runs, not of the kernel: one workgroup walks units of both kinds in list order, and the next unit's tile 0 is requested in ITS form
+// while the current unit's epilogue runs.  As in HybridStageFp8 the K DMA pieces of a tile are issued before its V register loads, so that
+// hipcc's counted vmcnt for the V data never waits on a younger DMA.
+template <int D, int NWAVES>
+struct MixStage {
+    using G = TileGeom<D, 2>;
+    using Dma = DmaStage<D, NWAVES, false, true>;
+    using VPath = BufStage<D, 2, NWAVES, false, false, true>;   // (its K half stays unused)
+    static constexpr int LOADS = Dma::LOADS;                     // pieces (DMA) or 16-byte loads per lane (registers) per tensor per tile
+    static constexpr int NL = 2 * LOADS, NW = LOADS;             // NW: ds_write_b128 per lane per tile, fp16 form only
+    static constexpr int KBLK = G::KBLK;
+    static constexpr bool K_DMA = true;
+    static_assert(VPath::LOADS == LOADS, "both V paths cut a tile the same way");
+    Dma d;
+    VPath v;
+    __device__ __forceinline__ void init(const char* Kh, const char* Vh, int64_t kS_bytes, int64_t vS_bytes, int S, int wave, int lane,
+                                         int row_bytes = D * 2) {
+        d.init(Kh, Vh, kS_bytes, vS_bytes, S, wave, lane, row_bytes);
+        v.init(Kh, Vh, kS_bytes, vS_bytes, S, wave, lane, row_bytes);
+    }
+    __device__ __forceinline__ void set_dst(lds_ptr slot) { d.set_dst(slot); }
+    template <int N, bool F16W>
+    __device__ __forceinline__ void load(int t) {
+        if constexpr (N < LOADS || !F16W) d.template load<N>(t);
+        else v.template load<N>(t);                              // (BufStage numbers its V loads LOADS .. 2 LOADS - 1 too)
+    }
+    template <int N, bool F16W>
+    __device__ __forceinline__ void write(lds_ptr slot_base) const {
+        if constexpr (F16W) v.template write<LOADS + N, true>(slot_base);
+    }
+    __device__ __forceinline__ void wait_all() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    template <bool F16W, int N = 0> __device__ __forceinline__ void load_all(int t) { if constexpr (N < NL) { load<N, F16W>(t); load_all<F16W, N + 1>(t); } }
+    template <bool F16W> __device__ __forceinline__ void load_all_into(int t, lds_ptr slot) { set_dst(slot); load_all<F16W>(t); }
+    template <bool F16W, int N = 0> __device__ __forceinline__ void write_all(lds_ptr s) const { if constexpr (N < NW) { write<N, F16W>(s); write_all<F16W, N + 1>(s); } }
 };
 
 // ---- fp8 inputs (Opt::dma, unpadded rows, 8 waves): K by LDS-DMA, V through registers -------------------------------------------

@@ -235,8 +235,9 @@ int flash_attention_plan(int batchSize, int numHeads, int seqLen, int dHead, boo
  * flash_attention_plan_ex -- what a flash_attention_ex() call with these arguments launches.  A bf16 problem may be split in two
  * ranges of query blocks (see "Precision of the softmax weights"): `early` describes the fp16-weights kernel over the first
  * early->q_blocks query blocks of every head, `main` the bf16-weights kernel over the remaining main->q_blocks; a range that
- * does not exist has q_blocks = 0 and grid = 0.  When both exist they run in ONE launch (every workgroup walks its main units,
- * then its early units): both descriptions then carry that launch's grid and LDS size.  lds_bytes is the launched
+ * does not exist has q_blocks = 0 and grid = 0.  When both exist they run in ONE launch of one kernel (every workgroup walks its
+ * share of the list of all query blocks; a unit runs in the precision of its block): both descriptions then carry that launch's
+ * grid and LDS size.  lds_bytes is the launched
  * instantiation's own figure (it depends on the engine, the staging form and the output type).  flash_attention_plan() is
  * this call with seqLenK = seqLen, flags = FA_FLAG_BF16_WEIGHTS (one range) and only `main` returned.  Either pointer may be NULL.
  */
@@ -244,9 +245,8 @@ typedef struct fa_launch_plan_ex {
     fa_launch_plan launch;
     int q_blocks;        /* query blocks of every head this range covers */
     int first_q_block;   /* ... starting at this one */
-    int unit_lists;      /* both ranges in one launch: 2 = each range walks a (head, query block) list of its own -- chosen where that
-                            schedule is balanced, the faster form --, 1 = both walk the list over all query blocks, each skipping the
-                            other's units (balanced for every shape); 0 = this is the only range */
+    int unit_lists;      /* 1 = both ranges run in ONE launch of one kernel that walks ONE (head, query block) list over all query blocks,
+                            every unit in the precision of its range; 0 = this is the only range (or the pair kernel's launch) */
 } fa_launch_plan_ex;
 
 int flash_attention_plan_ex(int batchSize, int numHeads, int seqLenQ, int seqLenK, int dHead, bool is_causal,

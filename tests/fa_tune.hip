@@ -77,9 +77,9 @@ static std::vector<Variant> make_variants() {
     constexpr int M = CAUSAL ? 0 : -1;   // production engine choice
     v.push_back({"production (16x16x32 non-causal, 32x32x16 causal), bf16 O", launch_cfg<ProdCfg<D, CAUSAL, T>>});
     v.push_back({"fp32 O (production)", launch_cfg<ProdCfg<D, CAUSAL, float>>, 4});
-    // the library's default call on a causal problem: two launches (include/flash_attention.h, "Precision of the softmax weights")
+    // the default precision as two launches of the single-precision kernels (what the mixed kernel replaces)
     if constexpr (CAUSAL) {
-        v.push_back({"fp32 O, library default: fp16 weights on query blocks 0-3, bf16 weights on the rest (two launches)",
+        v.push_back({"fp32 O, default precision as TWO launches: fp16-weights kernel on query blocks 0-3, bf16-weights kernel on the rest",
                      [](const Params& p, int grid) {
                          const int hp = std::min(p.nQ, 1024 / 256);
                          Params a = p, b = p;
@@ -88,27 +88,12 @@ static std::vector<Variant> make_variants() {
                          launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>(a, grid);
                          if (b.nQ > 0) launch_cfg<ProdCfg<D, CAUSAL, float>>(b, grid);
                      }, 4});
-        auto dual = [](const Params& p, bool two_lists) {
-            using CA = ProdCfg<D, CAUSAL, float>;
-            using CB = P16Cfg<D, CAUSAL, float>;
-            constexpr int lds = CA::LDS_BYTES > CB::LDS_BYTES ? CA::LDS_BYTES : CB::LDS_BYTES;
-            static bool once = [] {
-                HIP_CHECK(hipFuncSetAttribute((const void*)fwd_mfma_dual_kernel<CA, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                return true;
-            }();
-            (void)once;
-            const int hp = std::min(p.nQ, 1024 / 256);
-            Params a = p, b = p;
-            if (two_lists) {
-                a.qb0 = hp; a.nQ = p.nQ - hp; a.units = p.B * p.H * a.nQ; a.cpx = (a.units + 7) / 8;
-                b.qb0 = 0; b.nQ = hp; b.units = p.B * p.H * hp; b.cpx = (b.units + 7) / 8;
-            }
-            a.jpx = std::min(a.cpx, g_cus / 8);
-            b.jpx = std::min(b.cpx, g_cus / 8);
-            hipLaunchKernelGGL((fwd_mfma_dual_kernel<CA, CB>), dim3(8 * std::max(a.jpx, b.jpx)), dim3(512), lds, nullptr, p, unit_list_of(a), unit_list_of(b), hp);
-        };
-        v.push_back({"fp32 O, library default in ONE launch, two unit lists (late blocks, early blocks)", [dual](const Params& p, int) { dual(p, true); }, 4});
-        v.push_back({"fp32 O, library default in ONE launch, the single kernel's list walked twice", [dual](const Params& p, int) { dual(p, false); }, 4});
+        v.push_back({"fp32 O, library default: the MIXED kernel (one list, fp16 weights on query blocks 0-3)",
+                     [](const Params& p, int grid) { Params q = p; q.hp = std::min(p.nQ, 1024 / 256); launch_cfg<MixCfg<D, float>>(q, grid); }, 4});
+        v.push_back({"fp32 O, MIXED kernel, hp = 0 (bf16 weights everywhere: must equal the production kernel)",
+                     [](const Params& p, int grid) { Params q = p; q.hp = 0; launch_cfg<MixCfg<D, float>>(q, grid); }, 4});
+        v.push_back({"STAMP fp32 O, MIXED kernel",
+                     [](const Params& p, int grid) { Params q = p; q.hp = std::min(p.nQ, 1024 / 256); launch_cfg<MixCfg<D, float, true>>(q, grid); }, 4});
         v.push_back({"fp32 O, fp16 weights on query blocks 0-3 ONLY (the first of the two launches)",
                      [](const Params& p, int grid) {
                          const int hp = std::min(p.nQ, 1024 / 256);

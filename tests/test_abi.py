@@ -133,9 +133,9 @@ def test_plan_ex_describes_both_launches():
     early, main = fa.plan_ex(8, 16, 4096, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, 0)
     assert (early["first_q_block"], early["q_blocks"], main["first_q_block"], main["q_blocks"]) == (0, 4, 4, 12)
     assert early["grid"] == 256 and main["grid"] == 256 and early["threads"] == main["threads"] == 512      # ONE launch runs both ranges
-    assert early["unit_lists"] == main["unit_lists"] == 2      # 12 late blocks per head x 16 heads per XCD group = 6 whole rounds of 32: balanced
+    assert early["unit_lists"] == main["unit_lists"] == 1      # one kernel, one list over all 16 query blocks per head: every unit in its block's precision
     e2, m2 = fa.plan_ex(4, 16, 8192, 8192, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, 0)
-    assert (e2["q_blocks"], m2["q_blocks"], e2["unit_lists"], m2["unit_lists"]) == (4, 28, 1, 1)      # 8 heads x 28 blocks = 7 rounds: the snake's pairs do not close
+    assert (e2["q_blocks"], m2["q_blocks"], e2["unit_lists"], m2["unit_lists"]) == (4, 28, 1, 1)      # whatever the shape
     assert fa.plan_ex(8, 16, 4096, 4096, 128, False)[1]["unit_lists"] == 0
     assert early["lds_bytes"] == main["lds_bytes"] >= fa.plan(8, 16, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32)["lds_bytes"]
     early, main = fa.plan_ex(8, 16, 4096, 4096, 128, True, fa.FA_DTYPE_BF16, fa.FA_DTYPE_F32, fa.FA_FLAG_BF16_WEIGHTS)

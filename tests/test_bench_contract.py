@@ -160,12 +160,12 @@ def test_gpus_must_match_the_world():
 
 
 def test_roofline_kernel_name_comes_from_the_plan():
-    """roofline.kernel is what the library's own plan says the call launches (flash_attention_plan_ex), per workload: the
-    fused two-precision launch for the causal headline (rocprofv3 names it fa::fwd_mfma_dual_kernel:
-    profiles/r03_kernel_stats_cfg2.csv), the single persistent kernel without the mask, the pair kernel for cfg1's shape under the mask."""
+    """roofline.kernel is what the library's own plan says the call launches (flash_attention_plan_ex), per workload: the persistent
+    kernel (for the causal headline its mixed-precision instantiation -- config.kernel_variant says so; round 3 launched
+    fa::fwd_mfma_dual_kernel there: profiles/r03_kernel_stats_cfg2.csv), the pair kernel for cfg1's shape under the mask."""
     import __graft_entry__ as entry
     fa = entry.load_package()
-    want = {"cfg2": "fa::fwd_mfma_dual_kernel", "cfg2nc": "fa::fwd_mfma_kernel", "cfg1": "fa::fwd_mfma_kernel", "cfg1c": "fa::fwd_mfma_pair_kernel",
+    want = {"cfg2": "fa::fwd_mfma_kernel", "cfg2nc": "fa::fwd_mfma_kernel", "cfg1": "fa::fwd_mfma_kernel", "cfg1c": "fa::fwd_mfma_pair_kernel",
             "cfg4": "fa::fwd_mfma_kernel", "cfg3": "fa::fwd_mfma_kernel", "anchor": "fa::fwd_mfma_kernel"}
     for wl, name in want.items():
         B, H, S, d, causal, _ = bench.WORKLOADS[wl]
@@ -181,7 +181,8 @@ def test_roofline_kernel_name_comes_from_the_plan():
                        env=_clean_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert line["roofline"]["kernel"] == "fa::fwd_mfma_dual_kernel" and "traffic_ratio" in line["roofline"]
+    assert line["roofline"]["kernel"] == "fa::fwd_mfma_kernel" and "traffic_ratio" in line["roofline"]
+    assert line["config"]["kernel_variant"].startswith("mixed precision in one walk: fp16 weights on query blocks [0, 4), bf16 on [4, 16)")
     assert line["cfg4"]["roofline"]["kernel"] == "fa::fwd_mfma_kernel"
 
 
