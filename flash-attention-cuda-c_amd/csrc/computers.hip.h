@@ -314,14 +314,17 @@ struct WaveCompute {
 
     // ---- the slots -----------------------------------------------------------------------------
     // phase A slot I: fragment f = I/(MPF*R), then (sub, row group) = ((I % (MPF*R)) / R, I % R)
-    template <int I, bool DMA_A = true, bool F16W = false>
+    // QK = false: the wave's LAST tile -- there is no next tile to score: the slots keep their softmax slice, their DMA pieces and the
+    // first V^T fragments, the MFMAs and K fragment reads are left out (they were 1.5 % of a causal launch's MFMAs, computed for nothing)
+    template <int I, bool DMA_A = true, bool F16W = false, bool QK = true>
     __device__ __forceinline__ void slots_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase,
                                             float c, const Scores<R>& cur, Scores<R>& nxt) {
         if constexpr (I < SA) {
             constexpr int f = I / (MPF * R), rem = I % (MPF * R), sub = rem / R, rg = rem % R;
             if constexpr (C::VALU_FIRST) exp_slot<I, F16W>(cur, c);   // softmax slice covers the fragment's LDS latency
-            qk_mfma<f, sub, rg>(kf[(f + NPRE - 1) % NPRE], kf[f % NPRE], nxt);
-            if constexpr (C::MXQK) {
+            if constexpr (QK) qk_mfma<f, sub, rg>(kf[(f + NPRE - 1) % NPRE], kf[f % NPRE], nxt);
+            if constexpr (!QK) {
+            } else if constexpr (C::MXQK) {
                 // both fragments of a pair stay live until the pair's MFMA: refill the two window entries after it
                 if constexpr (rem == MPF * R - 1 && (f & 1)) {
                     if constexpr (f - 1 + NPRE < NF) kf[(f - 1) % NPRE] = k_read(k_next, kbase, f - 1 + NPRE);
@@ -337,7 +340,7 @@ struct WaveCompute {
             if constexpr (DMA_A) load_in_slot<I, F16W>(st, t_load);
             if constexpr (!C::VALU_FIRST) exp_slot<I, F16W>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
-            slots_a<I + 1, DMA_A, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+            slots_a<I + 1, DMA_A, F16W, QK>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         }
     }
     // phase B slot J: V^T fragment v = J/R (16-key step v/DB, d block v%DB), row group J%R
@@ -372,7 +375,7 @@ struct WaveCompute {
     // The step comes in two halves so that the staggered kernels (KernelCfg::STAG) can put the workgroup barrier between them
     // for half of the waves: tile_a = phase A, tile_b = phase B + the end-of-tile work.  DMA_A / DMA_B: which half issues the
     // wave's LDS-DMA pieces of tile t_load (the caller has set their destination: Stage::set_dst / set_dst2).
-    template <bool DMA_A = true, bool F16W = false>
+    template <bool DMA_A = true, bool F16W = false, bool QK = true>
     __device__ __forceinline__ void tile_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase, float c,
                                            const Scores<R>& cur, Scores<R>& nxt) {
 #pragma unroll
@@ -380,12 +383,14 @@ struct WaveCompute {
             sum_a[r] = sum_b[r] = 0.f;
             mx_a[r] = mx_b[r] = -INFINITY;
         }
-        zero(nxt);
+        if constexpr (QK) {
+            zero(nxt);
 #pragma unroll
-        for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
+            for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
+        }
         if constexpr (C::PRIO_A) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
-        slots_a<0, DMA_A, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        slots_a<0, DMA_A, F16W, QK>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         if constexpr (C::PRIO_A) {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);

@@ -46,6 +46,8 @@ struct Opt {
                                  // on v_mfma_f32_16x16x32_f16 (needs |V| <= 65504): FA_FLAG_F16_WEIGHTS, and by default the query blocks whose rows see few keys
     bool mix = false;            // 32x32x16 engine, LDS-DMA kernels: the units of the query blocks qb < Params::hp run with fp16 softmax weights (V staged
                                  // as fp16 through registers: MixStage), the others with bf16 weights, in list order inside ONE walk: the causal default
+    int lite = 0;                // 32x32x16 engine: 1 = a wave's LAST tile runs phase A without the QK^T MFMAs it would compute for nothing;
+                                 // 2 = ... and no wave stages tiles past the unit's last one
     int prio_a = -1;             // phase A of a tile step at s_setprio 1 (-1: on)
     int stag = 0;                // half-step stagger of the two waves of a SIMD (LDS-DMA kernels, 8 waves): 1 = waves 4-7 run half a tile step
                                  // behind waves 0-3 (their workgroup barrier sits between phase A and phase B), 2 = waves 0-3 behind waves 4-7.
@@ -64,6 +66,7 @@ struct KernelCfg {
     // of it.  +0.6 ... +1.3 % (causal and not, 21 / 15 interleaved rounds: profiles/r03_tune_j_phase_a_priority_*.log); static
     // priorities for one half of the waves measured nothing (r03_tune_e_*)
     static constexpr bool PRIO_A = O.prio_a != 0;
+    static constexpr int LITE = O.lite;
     // Cache policy of the output stores (utils.hip.h: store_global_b128): non-temporal under the causal mask -- O is written once and
     // never read, and every line it leaves in the XCD's L2 evicts K/V lines that the head's other query blocks are about to
     // re-read (causal, fp32 O: plain 1058, sc1 1073, nt 1076, sc0 sc1 1076 TFLOP/s; bf16 O +0.5 %; without the mask -0.3 %:
@@ -146,8 +149,8 @@ __device__ __forceinline__ bool block_or(bool v, lds_ptr flags, int wave) {
 
 // The causal default: the bf16-weights kernel whose units of the query blocks qb < Params::hp (the rows that see fewer than FA_EARLY_KEYS
 // keys) run with fp16 weights -- ONE walk over ONE (head, query block) list, every unit in the precision of its block
-template <int D, typename OutT, bool STAMP = false>
-using MixCfg = KernelCfg<D, true, OutT, 2, Opt{.stamp = STAMP, .m16 = 0, .mix = true}>;
+template <int D, typename OutT, bool STAMP = false, int LITE = 0>
+using MixCfg = KernelCfg<D, true, OutT, 2, Opt{.stamp = STAMP, .m16 = 0, .mix = true, .lite = LITE}>;
 
 // The per-wave compute engine of a configuration: 16x16x32 MFMAs (computers16.hip.h) or 32x32x16 (computers.hip.h).
 template <class C>
@@ -217,13 +220,27 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
         if constexpr (C::STAMP) t0 = cycle_stamp();
         if (kind != 2) {
             const bool has_next = kind == 0;
-            if constexpr (C::P_F16 || C::MIX)
+            if constexpr (C::LITE != 0 && !C::M16) {
+                // flavours of phase A (wave-uniform choices): no QK^T on the wave's last tile, no staging past the unit's last tile
+                st.set_dst(smem + so_wr);
+                const bool dma = C::LITE < 2 || t + AHEAD < n_tiles;
+                lds_ptr kn = smem + so_nxt, vc = smem + so_cur + KT;
+                if (has_next) {
+                    if (dma) w.template tile_a<true, F16W, true>(st, t + AHEAD, kn, vc, kbase, vbase, c, cur, nxt);
+                    else w.template tile_a<false, F16W, true>(st, t + AHEAD, kn, vc, kbase, vbase, c, cur, nxt);
+                } else {
+                    if (dma) w.template tile_a<true, F16W, false>(st, t + AHEAD, kn, vc, kbase, vbase, c, cur, nxt);
+                    else w.template tile_a<false, F16W, false>(st, t + AHEAD, kn, vc, kbase, vbase, c, cur, nxt);
+                }
+                w.template tile_b<TRACK, false, F16W>(st, t + AHEAD, smem + so_wr, vc, vbase, c, cur, nxt, has_next, has_next && needs_mask(t + 1),
+                                                      (t + 1) * KVBLK, q_row0, S, lane);
+            } else if constexpr (C::P_F16 || C::MIX)
                 w.template tile_step<TRACK, F16W>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
                                                   has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
             else
                 w.template tile_step<TRACK>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
                                             has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
-        } else {
+        } else if (C::LITE < 2 || t + AHEAD < n_tiles) {
             if constexpr (C::MIX) {
                 st.template load_all_into<F16W>(t + AHEAD, smem + so_wr);
                 st.template write_all<F16W>(smem + so_wr);

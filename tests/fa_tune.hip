@@ -90,6 +90,10 @@ static std::vector<Variant> make_variants() {
                      }, 4});
         v.push_back({"fp32 O, library default: the MIXED kernel (one list, fp16 weights on query blocks 0-3)",
                      [](const Params& p, int grid) { Params q = p; q.hp = std::min(p.nQ, 1024 / 256); launch_cfg<MixCfg<D, float>>(q, grid); }, 4});
+        v.push_back({"fp32 O, MIXED kernel + no QK^T on a wave's last tile (lite 1)",
+                     [](const Params& p, int grid) { Params q = p; q.hp = std::min(p.nQ, 1024 / 256); launch_cfg<MixCfg<D, float, false, 1>>(q, grid); }, 4});
+        v.push_back({"fp32 O, MIXED kernel + no QK^T on a wave's last tile, no staging past the last tile (lite 2)",
+                     [](const Params& p, int grid) { Params q = p; q.hp = std::min(p.nQ, 1024 / 256); launch_cfg<MixCfg<D, float, false, 2>>(q, grid); }, 4});
         v.push_back({"fp32 O, MIXED kernel, hp = 0 (bf16 weights everywhere: must equal the production kernel)",
                      [](const Params& p, int grid) { Params q = p; q.hp = 0; launch_cfg<MixCfg<D, float>>(q, grid); }, 4});
         v.push_back({"STAMP fp32 O, MIXED kernel",
@@ -213,10 +217,18 @@ int main(int argc, char** argv) {
     p.dbg = ddbg;
 
     std::vector<Variant> vars;
+#if defined(FA_TUNE_CAUSAL_D128)
+    if (fp8) { fprintf(stderr, "this build holds the causal d = 128 bf16 variants only\n"); return 2; }
+#else
     if (fp8 && d == 128) vars = causal ? make_variants_fp8<true>() : make_variants_fp8<false>();
+#endif
     else if (fp8) { fprintf(stderr, "--fp8 needs d = 128\n"); return 2; }
+#if defined(FA_TUNE_CAUSAL_D128)     // (a build with one problem class: a third of the compile time)
+    else if (d == 128 && causal) vars = make_variants<128, true>();
+#else
     else if (d == 128) vars = causal ? make_variants<128, true>() : make_variants<128, false>();
     else if (d == 64) vars = causal ? make_variants<64, true>() : make_variants<64, false>();
+#endif
     else { fprintf(stderr, "d must be 128 or 64\n"); return 2; }
     if (!only.empty()) {
         std::vector<Variant> sel;
