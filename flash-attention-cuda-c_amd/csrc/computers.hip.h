@@ -314,17 +314,14 @@ struct WaveCompute {
 
     // ---- the slots -----------------------------------------------------------------------------
     // phase A slot I: fragment f = I/(MPF*R), then (sub, row group) = ((I % (MPF*R)) / R, I % R)
-    // QK = false: the wave's LAST tile -- there is no next tile to score: the slots keep their softmax slice, their DMA pieces and the
-    // first V^T fragments, the MFMAs and K fragment reads are left out (they were 1.5 % of a causal launch's MFMAs, computed for nothing)
-    template <int I, bool DMA_A = true, bool F16W = false, bool QK = true>
+    template <int I, bool F16W = false>
     __device__ __forceinline__ void slots_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase,
                                             float c, const Scores<R>& cur, Scores<R>& nxt) {
         if constexpr (I < SA) {
             constexpr int f = I / (MPF * R), rem = I % (MPF * R), sub = rem / R, rg = rem % R;
             if constexpr (C::VALU_FIRST) exp_slot<I, F16W>(cur, c);   // softmax slice covers the fragment's LDS latency
-            if constexpr (QK) qk_mfma<f, sub, rg>(kf[(f + NPRE - 1) % NPRE], kf[f % NPRE], nxt);
-            if constexpr (!QK) {
-            } else if constexpr (C::MXQK) {
+            qk_mfma<f, sub, rg>(kf[(f + NPRE - 1) % NPRE], kf[f % NPRE], nxt);
+            if constexpr (C::MXQK) {
                 // both fragments of a pair stay live until the pair's MFMA: refill the two window entries after it
                 if constexpr (rem == MPF * R - 1 && (f & 1)) {
                     if constexpr (f - 1 + NPRE < NF) kf[(f - 1) % NPRE] = k_read(k_next, kbase, f - 1 + NPRE);
@@ -337,15 +334,15 @@ struct WaveCompute {
                 constexpr int v = I - (SA - VPRE);
                 vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DB, v % DB);
             }
-            if constexpr (DMA_A) load_in_slot<I, F16W>(st, t_load);
+            load_in_slot<I, F16W>(st, t_load);
             if constexpr (!C::VALU_FIRST) exp_slot<I, F16W>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
-            slots_a<I + 1, DMA_A, F16W, QK>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+            slots_a<I + 1, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         }
     }
     // phase B slot J: V^T fragment v = J/R (16-key step v/DB, d block v%DB), row group J%R
-    template <bool TRACK, int J, bool DMA_B = false, bool F16W = false>
-    __device__ __forceinline__ void slots_b(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
+    template <bool TRACK, int J, bool F16W = false>
+    __device__ __forceinline__ void slots_b(Stage& st, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
                                             const Scores<R>& cur, const Scores<R>& nxt) {
         if constexpr (J < SB) {
             constexpr int v = J / R, rg = J % R, s4 = v / DB, db = v % DB;
@@ -355,7 +352,6 @@ struct WaveCompute {
                 constexpr int vn = v + VPRE;
                 vf[vn % (VPRE + 1)] = v_frag(v_cur, vbase, vn / DB, vn % DB);
             }
-            if constexpr (DMA_B) load_in_slot<J, F16W>(st, t_load);
             exp_slot<SA + J, F16W>(cur, c);
             if constexpr (TRACK && J < SB / 2) max3_slot<J>(nxt);
             if constexpr (TRACK && J == SB / 2) decide(c);
@@ -364,7 +360,7 @@ struct WaveCompute {
                 else st.template write<(J - SB / 2) / WSTEP>(wr_slot);
             }
             __builtin_amdgcn_sched_barrier(0);
-            slots_b<TRACK, J + 1, DMA_B, F16W>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt);
+            slots_b<TRACK, J + 1, F16W>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         }
     }
 
@@ -372,36 +368,28 @@ struct WaveCompute {
     // does not need and ignored: one hot code path).
     // TRACK = true: running row max with lazy rescale (always safe).  TRACK = false: the optimistic
     // pass -- m stays the row max of tile 0 and no max / decision / rescale is issued.
-    // The step comes in two halves so that the staggered kernels (KernelCfg::STAG) can put the workgroup barrier between them
-    // for half of the waves: tile_a = phase A, tile_b = phase B + the end-of-tile work.  DMA_A / DMA_B: which half issues the
-    // wave's LDS-DMA pieces of tile t_load (the caller has set their destination: Stage::set_dst / set_dst2).
-    template <bool DMA_A = true, bool F16W = false, bool QK = true>
-    __device__ __forceinline__ void tile_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase, float c,
-                                           const Scores<R>& cur, Scores<R>& nxt) {
+    template <bool TRACK, bool F16W = false>
+    __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
+                                              int kbase, int vbase, float c, const Scores<R>& cur, Scores<R>& nxt,
+                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
+        st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             sum_a[r] = sum_b[r] = 0.f;
             mx_a[r] = mx_b[r] = -INFINITY;
         }
-        if constexpr (QK) {
-            zero(nxt);
+        zero(nxt);
 #pragma unroll
-            for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
-        }
+        for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
         if constexpr (C::PRIO_A) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
-        slots_a<0, DMA_A, F16W, QK>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        slots_a<0, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         if constexpr (C::PRIO_A) {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (C::STAMP) t_mid = cycle_stamp();
-    }
-    template <bool TRACK, bool DMA_B = false, bool F16W = false>
-    __device__ __forceinline__ void tile_b(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
-                                           const Scores<R>& cur, Scores<R>& nxt,
-                                           bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
-        slots_b<TRACK, 0, DMA_B, F16W>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt);
+        slots_b<TRACK, 0, F16W>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
 #pragma unroll
         for (int r = 0; r < R; ++r) l[r] += sum_a[r] + sum_b[r];
@@ -431,14 +419,6 @@ struct WaveCompute {
                 }
             }
         }
-    }
-    template <bool TRACK, bool F16W = false>
-    __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
-                                              int kbase, int vbase, float c, const Scores<R>& cur, Scores<R>& nxt,
-                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
-        st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
-        tile_a<true, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
-        tile_b<TRACK, false, F16W>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt, has_next, mask_next, kv0_next, q_row0, S, lane);
     }
 
     // True iff a row sum or any O accumulator of this lane is inf / NaN (x*0 is NaN for both).  Four independent

@@ -296,7 +296,7 @@ struct WaveCompute16 {
 
     // ---- the slots -----------------------------------------------------------------------------
     // phase A slot I: K fragment f = I / QG, query group I % QG
-    template <int I, bool DMA_A = true, bool F16W = C::P_F16>
+    template <int I, bool F16W = C::P_F16>
     __device__ __forceinline__ void slots_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase,
                                             float c, const Scores16& cur, Scores16& nxt) {
         if constexpr (I < SA) {
@@ -308,15 +308,15 @@ struct WaveCompute16 {
                 constexpr int v = I - (SA - VPRE);
                 vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DG, v % DG);
             }
-            if constexpr (DMA_A) load_in_slot<I>(st, t_load);
+            load_in_slot<I>(st, t_load);
             if constexpr (!C::VALU_FIRST) exp_slot<I, F16W>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
-            slots_a<I + 1, DMA_A, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+            slots_a<I + 1, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         }
     }
     // phase B slot J: V^T fragment v = J / QG (k-step v / DG, d group v % DG), query group J % QG
-    template <bool TRACK, int J, bool DMA_B = false, bool F16W = C::P_F16>
-    __device__ __forceinline__ void slots_b(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
+    template <bool TRACK, int J, bool F16W = C::P_F16>
+    __device__ __forceinline__ void slots_b(Stage& st, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
                                             const Scores16& cur, const Scores16& nxt) {
         if constexpr (J < SB) {
             constexpr int v = J / QG, qg = J % QG, kk = v / DG, dg = v % DG;
@@ -326,43 +326,39 @@ struct WaveCompute16 {
                 constexpr int vn = v + VPRE;
                 vf[vn % (VPRE + 1)] = v_frag(v_cur, vbase, vn / DG, vn % DG);
             }
-            if constexpr (DMA_B) load_in_slot<J>(st, t_load);
             exp_slot<SA + J, F16W>(cur, c);
             if constexpr (TRACK && J < SB / 2) max3_slot<J>(nxt);
             if constexpr (TRACK && J == SB / 2) decide(c);
             if constexpr (J >= SB / 2 && (J - SB / 2) % WSTEP == 0 && (J - SB / 2) / WSTEP < NW)
                 st.template write<(J - SB / 2) / WSTEP, F16W>(wr_slot);
             __builtin_amdgcn_sched_barrier(0);
-            slots_b<TRACK, J + 1, DMA_B, F16W>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt);
+            slots_b<TRACK, J + 1, F16W>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         }
     }
 
-    // One tile: cur = S(t) (consumed), nxt = S(t+1) (produced).  Same contract as WaveCompute::tile_step / tile_a / tile_b.
-    template <bool DMA_A = true, bool F16W = C::P_F16>
-    __device__ __forceinline__ void tile_a(Stage& st, int t_load, lds_ptr k_next, lds_ptr v_cur, int kbase, int vbase, float c,
-                                           const Scores16& cur, Scores16& nxt) {
+    // One tile: cur = S(t) (consumed), nxt = S(t+1) (produced).  Same contract as WaveCompute::tile_step.
+    template <bool TRACK, bool F16W = C::P_F16>
+    __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
+                                              int kbase, int vbase, float c, const Scores16& cur, Scores16& nxt,
+                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
             mx_a[qg] = mx_b[qg] = -INFINITY;
             sum_a[qg] = sum_b[qg] = 0.f;
         }
         zero(nxt);
+        st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) kf[i] = k_read(k_next, kbase, i);
         if constexpr (C::PRIO_A) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
-        slots_a<0, DMA_A, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
+        slots_a<0, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
         if constexpr (C::PRIO_A) {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (C::STAMP) t_mid = cycle_stamp();
-    }
-    template <bool TRACK, bool DMA_B = false, bool F16W = C::P_F16>
-    __device__ __forceinline__ void tile_b(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr v_cur, int vbase, float c,
-                                           const Scores16& cur, Scores16& nxt,
-                                           bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
-        slots_b<TRACK, 0, DMA_B, F16W>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt);
+        slots_b<TRACK, 0, F16W>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
         if constexpr (!C::SUM_MFMA) {
 #pragma unroll
@@ -391,14 +387,6 @@ struct WaveCompute16 {
                 }
             }
         }
-    }
-    template <bool TRACK, bool F16W = C::P_F16>
-    __device__ __forceinline__ void tile_step(Stage& st, int t_load, lds_ptr wr_slot, lds_ptr k_next, lds_ptr v_cur,
-                                              int kbase, int vbase, float c, const Scores16& cur, Scores16& nxt,
-                                              bool has_next, bool mask_next, int kv0_next, int q_row0, int S, int lane) {
-        st.set_dst(wr_slot);   // (LDS-DMA staging: where this iteration's loads land)
-        tile_a<true, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);
-        tile_b<TRACK, false, F16W>(st, t_load, wr_slot, v_cur, vbase, c, cur, nxt, has_next, mask_next, kv0_next, q_row0, S, lane);
     }
 
     // True iff a row sum or any O accumulator of this lane is inf / NaN (x*0 is NaN for both); four independent chains.

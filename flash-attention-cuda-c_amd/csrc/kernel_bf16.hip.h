@@ -46,12 +46,6 @@ struct Opt {
                                  // on v_mfma_f32_16x16x32_f16 (needs |V| <= 65504): FA_FLAG_F16_WEIGHTS, and by default the query blocks whose rows see few keys
     bool mix = false;            // 32x32x16 engine, LDS-DMA kernels: the units of the query blocks qb < Params::hp run with fp16 softmax weights (V staged
                                  // as fp16 through registers: MixStage), the others with bf16 weights, in list order inside ONE walk: the causal default
-    int lite = 0;                // 32x32x16 engine: 1 = a wave's LAST tile runs phase A without the QK^T MFMAs it would compute for nothing;
-                                 // 2 = ... and no wave stages tiles past the unit's last one
-    int prio_a = -1;             // phase A of a tile step at s_setprio 1 (-1: on)
-    int stag = 0;                // half-step stagger of the two waves of a SIMD (LDS-DMA kernels, 8 waves): 1 = waves 4-7 run half a tile step
-                                 // behind waves 0-3 (their workgroup barrier sits between phase A and phase B), 2 = waves 0-3 behind waves 4-7.
-                                 // A wave in phase A (K reads, exponentials) then always shares its SIMD with one in phase B (attention_pass_stag)
 };
 
 template <int D_, bool CAUSAL_, typename OutT_, int ESZ_ = 2, Opt O = Opt{}>
@@ -65,8 +59,7 @@ struct KernelCfg {
     // exponentials) at s_setprio 1 and phase B (P.V) at 0: of the two waves of a SIMD the one still in phase A outranks the one ahead
     // of it.  +0.6 ... +1.3 % (causal and not, 21 / 15 interleaved rounds: profiles/r03_tune_j_phase_a_priority_*.log); static
     // priorities for one half of the waves measured nothing (r03_tune_e_*)
-    static constexpr bool PRIO_A = O.prio_a != 0;
-    static constexpr int LITE = O.lite;
+    static constexpr bool PRIO_A = true;
     // Cache policy of the output stores (utils.hip.h: store_global_b128): non-temporal under the causal mask -- O is written once and
     // never read, and every line it leaves in the XCD's L2 evicts K/V lines that the head's other query blocks are about to
     // re-read (causal, fp32 O: plain 1058, sc1 1073, nt 1076, sc0 sc1 1076 TFLOP/s; bf16 O +0.5 %; without the mask -0.3 %:
@@ -101,19 +94,10 @@ struct KernelCfg {
     static constexpr int QBLK = 32 * NWAVES;         // query rows of a unit
     static constexpr int RING = 3;                   // LDS ring slots: tile t+2 is staged in iteration t
     static constexpr int RING_BYTES = RING * TileGeom<D_, ESZ_>::SLOT;
-    // Staggered kernels: the lagging waves read V(t-1) in the barrier interval in which the leading ones read V(t), so the same 3 slots
-    // are cut as a K ring of 2 (K(t) in the K half of slot t & 1) and a V ring of 4 (the V halves of slots 0, 1 and the two halves
-    // of slot 2): tile t+2 still arrives in interval t, into places whose last readers left at the previous barrier
-    static constexpr int STAG = (DMA && O.waves == 8) ? O.stag : 0;
-    static_assert(O.stag == 0 || (DMA && O.waves == 8), "the stagger is built for the LDS-DMA kernels with 8 waves");
-    // query rows of a wave inside its unit: under the causal mask the LAGGING half takes the rows that see fewer keys (its tail hides
-    // behind the leading half's diagonal tiles)
-    __host__ __device__ static constexpr int row_group(int wave) { return (STAG == 1 && CAUSAL_) ? ((wave + O.waves / 2) & (O.waves - 1)) : wave; }
     // LDS-DMA staging: the epilogue regions (QBLK rows of D 2-byte outputs, or of 64 floats) sit behind ring slot 0
     static constexpr int EP_OFF = (DMA || DMA_K8) ? TileGeom<D_, ESZ_>::SLOT : 0;
     static constexpr int EP_NEED = EP_OFF + (sizeof(OutT_) == 2 ? QBLK * D_ * 2 : QBLK * 256);
-    static constexpr int DUMP_OFF = EP_NEED > RING_BYTES ? EP_NEED : RING_BYTES;   // the stagger's dump slot: behind the ring AND the epilogue regions
-    static constexpr int FLAG_OFF = DUMP_OFF + (STAG ? TileGeom<D_, ESZ_>::SLOT : 0);   // one word per wave: "my result is not finite" (block_or)
+    static constexpr int FLAG_OFF = EP_NEED > RING_BYTES ? EP_NEED : RING_BYTES;   // behind everything: one word per wave, "my result is not finite" (block_or)
     static constexpr int LDS_BYTES = FLAG_OFF + 64;
     static_assert(LDS_BYTES <= 163840, "160 KiB of LDS per CU");
 };
@@ -149,8 +133,8 @@ __device__ __forceinline__ bool block_or(bool v, lds_ptr flags, int wave) {
 
 // The causal default: the bf16-weights kernel whose units of the query blocks qb < Params::hp (the rows that see fewer than FA_EARLY_KEYS
 // keys) run with fp16 weights -- ONE walk over ONE (head, query block) list, every unit in the precision of its block
-template <int D, typename OutT, bool STAMP = false, int LITE = 0>
-using MixCfg = KernelCfg<D, true, OutT, 2, Opt{.stamp = STAMP, .m16 = 0, .mix = true, .lite = LITE}>;
+template <int D, typename OutT, bool STAMP = false>
+using MixCfg = KernelCfg<D, true, OutT, 2, Opt{.stamp = STAMP, .m16 = 0, .mix = true}>;
 
 // The per-wave compute engine of a configuration: 16x16x32 MFMAs (computers16.hip.h) or 32x32x16 (computers.hip.h).
 template <class C>
@@ -220,27 +204,13 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
         if constexpr (C::STAMP) t0 = cycle_stamp();
         if (kind != 2) {
             const bool has_next = kind == 0;
-            if constexpr (C::LITE != 0 && !C::M16) {
-                // flavours of phase A (wave-uniform choices): no QK^T on the wave's last tile, no staging past the unit's last tile
-                st.set_dst(smem + so_wr);
-                const bool dma = C::LITE < 2 || t + AHEAD < n_tiles;
-                lds_ptr kn = smem + so_nxt, vc = smem + so_cur + KT;
-                if (has_next) {
-                    if (dma) w.template tile_a<true, F16W, true>(st, t + AHEAD, kn, vc, kbase, vbase, c, cur, nxt);
-                    else w.template tile_a<false, F16W, true>(st, t + AHEAD, kn, vc, kbase, vbase, c, cur, nxt);
-                } else {
-                    if (dma) w.template tile_a<true, F16W, false>(st, t + AHEAD, kn, vc, kbase, vbase, c, cur, nxt);
-                    else w.template tile_a<false, F16W, false>(st, t + AHEAD, kn, vc, kbase, vbase, c, cur, nxt);
-                }
-                w.template tile_b<TRACK, false, F16W>(st, t + AHEAD, smem + so_wr, vc, vbase, c, cur, nxt, has_next, has_next && needs_mask(t + 1),
-                                                      (t + 1) * KVBLK, q_row0, S, lane);
-            } else if constexpr (C::P_F16 || C::MIX)
+if constexpr (C::P_F16 || C::MIX)
                 w.template tile_step<TRACK, F16W>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
                                                   has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
             else
                 w.template tile_step<TRACK>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
                                             has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
-        } else if (C::LITE < 2 || t + AHEAD < n_tiles) {
+        } else {
             if constexpr (C::MIX) {
                 st.template load_all_into<F16W>(t + AHEAD, smem + so_wr);
                 st.template write_all<F16W>(smem + so_wr);
@@ -269,113 +239,6 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
         if (t + 1 < n_tiles) step(t + 1, kind_of(t + 1), sB, sA);
     }
     if constexpr (TRACK && !F16W) return false;
-    else {
-        unsigned long long tc0 = 0;
-        if constexpr (C::STAMP) tc0 = cycle_stamp();
-        const bool bad = block_or<C::NWAVES>(my_tiles > 0 && w.not_finite(), smem + C::FLAG_OFF, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
-        if constexpr (C::STAMP) acc[10] += cycle_stamp() - tc0;
-        return bad;
-    }
-}
-
-// The staggered form of attention_pass (KernelCfg::STAG).  The two waves of a SIMD run the same program; in attention_pass both enter
-// phase A behind the barrier together, compete for the SIMD's vector issue through its exponentials and K reads (the younger wave's phase
-// A takes 1.25 x the older one's) and meet again at the next barrier, where the older wave waits 600-700 cycles per tile.  Here half of
-// the waves (LAG) run HALF A TILE STEP behind the others: their barrier sits between phase A and phase B,
-//     leading waves:   A(t) B(t) | barrier | A(t+1) B(t+1) | barrier ...
-//     lagging waves:        A(t) | barrier | B(t) A(t+1)   | barrier | B(t+1) ...
-// so a wave in phase A always shares its SIMD with a wave in phase B.  Same instruction sequence per wave, same results bit for bit.
-// What moves is which LDS tiles are live together: in interval t the leading waves read K(t+1), V(t), the lagging ones V(t-1), K(t+1),
-// and tile t+2 arrives -- hence the K ring of 2 and V ring of 4 (KernelCfg::STAG).  A lagging wave issues its DMA pieces at the START of
-// an interval like everyone else, i.e. in its phase B: B(t) carries tile t+3 (its pieces of tile 2 go out behind the prologue), and only
-// while a barrier still follows (t + 1 < n_tiles): the last B runs behind the pass's last barrier.
-template <class C, bool TRACK, bool LAG>
-__device__ __forceinline__ bool attention_pass_stag(const Params& p, WaveComputeOf<C>& w, typename WaveComputeOf<C>::Stage& st, lds_ptr smem,
-                                                    int n_tiles, int my_tiles, int q_row0, int lane,
-                                                    unsigned long long (&acc)[24], bool tile0_in_flight) {
-    using G = TileGeom<C::D, C::ESZ>;
-    using WC = WaveComputeOf<C>;
-    constexpr bool CAUSAL = C::CAUSAL;
-    constexpr int KVBLK = 64, SLOT = G::SLOT, KT = G::K_TILE, VT = G::V_TILE;
-    static_assert(KT == VT && WC::Stage::K_DMA, "K ring of 2 + V ring of 4 in three [K | V] slots");
-    auto k_img = [&](int t) { return smem + (t & 1) * SLOT; };
-    auto v_img = [&](int t) { return smem + ((t & 2) ? 2 * SLOT + (t & 1) * VT : (t & 1) * SLOT + KT); };
-    const int S = p.Sk;   // key bound of the masks
-    unsigned long long tp0 = 0, tp1 = 0, tp2 = 0;
-    if constexpr (C::STAMP) tp0 = cycle_stamp();
-    w.init();
-    constexpr int KBLK = (G::ROWB / 16) * 128;
-    const int kbase = C::M16 ? kd16_read_base(lane, KBLK) : kd_read_base(lane, KBLK);
-    const int vbase = C::M16 ? v16_read_base<C::D>(lane) : v_read_base(lane);
-    const float c = p.scale_log2;
-    auto needs_mask = [&](int t) { return (CAUSAL && t * KVBLK + KVBLK - 1 > q_row0) || (t * KVBLK + KVBLK > S); };
-    typename WC::ScoresT sA, sB;
-
-    // Prologue, as in attention_pass: tile 0 = [K slot 0 | V slot 0], tile 1 = [K slot 1 | V slot 1]
-    if (!tile0_in_flight) st.load_all_into(0, smem);
-    unsigned long long tw0 = 0;
-    if constexpr (C::STAMP) tw0 = cycle_stamp();
-    st.wait_all();
-    if constexpr (C::STAMP) acc[16] += cycle_stamp() - tw0;
-    __syncthreads();
-    st.load_all_into(1, smem + SLOT);
-    if constexpr (C::STAMP) tp1 = cycle_stamp();
-    if (my_tiles > 0) {
-        w.qk_all(smem, kbase, sA);
-        if (needs_mask(0)) w.mask(sA, 0, q_row0, S, lane);
-        w.first_max(sA, c);
-    }
-    st.wait_all();
-    __syncthreads();
-    if constexpr (LAG) st.load_all_into2(2, k_img(2), v_img(2));   // K slot 0 is free behind this barrier: every wave has scored tile 0
-    if constexpr (C::STAMP) { tp2 = cycle_stamp(); acc[8] += tp1 - tp0; acc[9] += tp2 - tp1; }
-
-    // kind: 0 = full step, 1 = the wave's last tile, 2 = staging only (attention_pass)
-    auto step = [&](int t, int kind, typename WC::ScoresT& cur, typename WC::ScoresT& nxt) {
-        unsigned long long t0 = 0, ta = 0, t4 = 0, t6 = 0;
-        if constexpr (C::STAMP) t0 = cycle_stamp();
-        const bool has_next = kind == 0;
-        const bool mask_next = has_next && needs_mask(t + 1);
-        if constexpr (!LAG) {
-            st.set_dst2(k_img(t + 2), v_img(t + 2));
-            if (kind != 2) {
-                w.template tile_a<true>(st, t + 2, k_img(t + 1), v_img(t), kbase, vbase, c, cur, nxt);
-                if constexpr (C::STAMP) ta = w.t_mid;
-                w.template tile_b<TRACK, false>(st, t + 2, smem, v_img(t), vbase, c, cur, nxt, has_next, mask_next, (t + 1) * KVBLK, q_row0, S, lane);
-            } else {
-                st.load_all(t + 2);
-            }
-            if constexpr (C::STAMP) t4 = cycle_stamp();
-            st.wait_all();
-            __syncthreads();
-            if constexpr (C::STAMP) {
-                t6 = cycle_stamp();
-                if (kind != 2) { acc[1] += ta - t0; acc[2] += w.t_end - ta; acc[3] += t4 - w.t_end; acc[6] += 1; }
-                acc[5] += t6 - t4;
-            }
-        } else {
-            if (kind != 2) w.template tile_a<false>(st, 0, k_img(t + 1), v_img(t), kbase, vbase, c, cur, nxt);
-            if constexpr (C::STAMP) t4 = cycle_stamp();
-            st.wait_all();   // (the pieces issued in the previous phase B)
-            __syncthreads();
-            if constexpr (C::STAMP) t6 = cycle_stamp();
-            // the last B of the pass runs behind its last barrier: its pieces (nobody needs them) go to a dump region behind the ring
-            const bool dma = t + 1 < n_tiles;
-            st.set_dst2(dma ? k_img(t + 3) : smem + C::DUMP_OFF, dma ? v_img(t + 3) : smem + C::DUMP_OFF + KT);
-            if (kind != 2) w.template tile_b<TRACK, true>(st, t + 3, smem, v_img(t), vbase, c, cur, nxt, has_next, mask_next, (t + 1) * KVBLK, q_row0, S, lane);
-            else st.load_all(t + 3);
-            if constexpr (C::STAMP) {
-                if (kind != 2) { acc[1] += t4 - t0; acc[2] += w.t_end - t6; acc[3] += cycle_stamp() - w.t_end; acc[6] += 1; }
-                acc[5] += t6 - t4;
-            }
-        }
-    };
-    auto kind_of = [&](int t) { return t + 1 < my_tiles ? 0 : (t < my_tiles ? 1 : 2); };
-    for (int t = 0; t < n_tiles; t += 2) {
-        step(t, kind_of(t), sA, sB);
-        if (t + 1 < n_tiles) step(t + 1, kind_of(t + 1), sB, sA);
-    }
-    if constexpr (TRACK) return false;
     else {
         unsigned long long tc0 = 0;
         if constexpr (C::STAMP) tc0 = cycle_stamp();
@@ -424,7 +287,7 @@ struct UnitCtx {
         Vh = (const char*)p.V + (b * p.vB + h * p.vH) * ESZ;
         Oh = (char*)p.O + (b * p.oB + h * p.oH) * (int64_t)sizeof(typename C::OutT);
         lse_head = p.lse ? p.lse + (int64_t)g * p.S : nullptr;
-        q_row0 = qb * QBLK + C::row_group(wave) * WROWS; // first query row of this wave
+        q_row0 = qb * QBLK + wave * WROWS;              // first query row of this wave
         const int q_end = min(p.S, (qb + 1) * QBLK);    // one past the last query row of the block
         const int k_tiles = (p.Sk + KVBLK - 1) / KVBLK;
         n_tiles = C::CAUSAL ? min(k_tiles, (q_end + KVBLK - 1) / KVBLK) : k_tiles;
@@ -502,17 +365,7 @@ __device__ __forceinline__ void run_units(const Params& p, const UnitList& L, ld
         // An opaque copy of the lane id keeps them inside the pass.
         int lane_p = lane;
         asm volatile("" : "+v"(lane_p));
-        if constexpr (C::STAG != 0) {
-            // (wave-uniform: `wave` comes out of readfirstlane.  Both branches hold the same number of barriers.)
-            const bool lag = (wave >= C::NWAVES / 2) == (C::STAG == 1);
-            bool again;
-            if (lag) again = attention_pass_stag<C, false, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true);
-            else again = attention_pass_stag<C, false, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, true);
-            if (again) {
-                if (lag) attention_pass_stag<C, true, true>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false);
-                else attention_pass_stag<C, true, false>(p, w, st, smem, cur.n_tiles, cur.my_tiles, cur.q_row0, lane_p, acc, false);
-            }
-        } else if constexpr (C::MIX) {
+        if constexpr (C::MIX) {
             // both precisions in one walk: the unit's query block says which.  An fp16 unit whose passes come out non-finite (V beyond
             // fp16's range, see below) is repeated by the bf16-weights tracked pass -- the one a bf16 unit falls back to anyway
             if (cur.early) {

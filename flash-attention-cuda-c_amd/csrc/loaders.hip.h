@@ -265,7 +265,7 @@ struct DmaStage {
     int ktile, vtile;      // bytes per 64-key tile step (scalar)
     int kgrp, vgrp;        // bytes per 8-key group step in global memory (scalar)
     int kdst, vdst;        // this wave's first block inside the K / V image (scalar)
-    uint32_t dst, dstv;    // LDS byte addresses of the K image / the V image the next loads go to (scalar)
+    uint32_t dst;          // LDS byte address of the ring slot the next loads go to (scalar)
     __device__ __forceinline__ static u32x4 descriptor(uint64_t a, uint32_t bytes) {
         return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
     }
@@ -284,11 +284,9 @@ struct DmaStage {
         voff = V16 ? (8 * g0 + ((lane >> 1) & 7)) * (int)vS_bytes + (2 * (lane >> 4) + (lane & 1)) * 16
                    : (8 * g0 + ((lane >> 2) & 7)) * (int)vS_bytes + (4 * (lane >> 5) + (lane & 3)) * 16;
         kdst = g0 * KBLK;
-        vdst = g0 * VBLK;
+        vdst = G::K_TILE + g0 * VBLK;
     }
-    // a ring slot [K image | V image], or (the staggered kernels' K ring of 2 + V ring of 4: kernel_bf16.hip.h) the two images on their own
-    __device__ __forceinline__ void set_dst(lds_ptr slot) { set_dst2(slot, slot + G::K_TILE); }
-    __device__ __forceinline__ void set_dst2(lds_ptr kimg, lds_ptr vimg) { dst = (uint32_t)(uintptr_t)kimg; dstv = (uint32_t)(uintptr_t)vimg; }
+    __device__ __forceinline__ void set_dst(lds_ptr slot) { dst = (uint32_t)(uintptr_t)slot; }
     // The DMA is issued from inline asm: hipcc then keeps no account of it -- issued through the builtin, every ds_read_b64_tr_b16 that
     // follows waits vmcnt(0) for it (the V^T reads of the SAME iteration), because the waitcnt pass cannot tell the ring slots apart.
     // Ordering is by hand instead: wait_all() before the barrier that publishes the tile.  M0 (the LDS destination) is written in the
@@ -307,7 +305,7 @@ struct DmaStage {
     __device__ __forceinline__ void load(int t) const {
         constexpr int n = N < LOADS ? N : N - LOADS, gi = n / HALVES, j = n % HALVES;
         if constexpr (N < LOADS) dma16(krsrc, dst + kdst + gi * KBLK + j * 1024, koff[gi] + t * ktile + j * 128);
-        else dma16(vrsrc, dstv + vdst + gi * VBLK + j * 1024, voff + t * vtile + gi * vgrp + j * 128);
+        else dma16(vrsrc, dst + vdst + gi * VBLK + j * 1024, voff + t * vtile + gi * vgrp + j * 128);
     }
     // every piece this wave has issued has landed in LDS (then a barrier publishes it to the other waves)
     __device__ __forceinline__ void wait_all() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -315,7 +313,6 @@ struct DmaStage {
     __device__ __forceinline__ void write(lds_ptr) const {}
     template <int N = 0> __device__ __forceinline__ void load_all(int t) const { if constexpr (N < NL) { load<N>(t); load_all<N + 1>(t); } }
     __device__ __forceinline__ void load_all_into(int t, lds_ptr slot) { set_dst(slot); load_all(t); }
-    __device__ __forceinline__ void load_all_into2(int t, lds_ptr kimg, lds_ptr vimg) { set_dst2(kimg, vimg); load_all(t); }
     __device__ __forceinline__ void write_all(lds_ptr) const {}
 };
 

@@ -90,10 +90,6 @@ static std::vector<Variant> make_variants() {
                      }, 4});
         v.push_back({"fp32 O, library default: the MIXED kernel (one list, fp16 weights on query blocks 0-3)",
                      [](const Params& p, int grid) { Params q = p; q.hp = std::min(p.nQ, 1024 / 256); launch_cfg<MixCfg<D, float>>(q, grid); }, 4});
-        v.push_back({"fp32 O, MIXED kernel + no QK^T on a wave's last tile (lite 1)",
-                     [](const Params& p, int grid) { Params q = p; q.hp = std::min(p.nQ, 1024 / 256); launch_cfg<MixCfg<D, float, false, 1>>(q, grid); }, 4});
-        v.push_back({"fp32 O, MIXED kernel + no QK^T on a wave's last tile, no staging past the last tile (lite 2)",
-                     [](const Params& p, int grid) { Params q = p; q.hp = std::min(p.nQ, 1024 / 256); launch_cfg<MixCfg<D, float, false, 2>>(q, grid); }, 4});
         v.push_back({"fp32 O, MIXED kernel, hp = 0 (bf16 weights everywhere: must equal the production kernel)",
                      [](const Params& p, int grid) { Params q = p; q.hp = 0; launch_cfg<MixCfg<D, float>>(q, grid); }, 4});
         v.push_back({"STAMP fp32 O, MIXED kernel",
@@ -132,14 +128,7 @@ static std::vector<Variant> make_variants() {
     v.push_back({"the other engine", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.m16 = CAUSAL ? 1 : 0}>>});
     v.push_back({"fp16 weights (FA_FLAG_F16_WEIGHTS)", launch_cfg<KernelCfg<D, CAUSAL, T, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>});
     v.push_back({"exact row sums (the LSE instantiation)", launch_cfg<ProdCfg<D, CAUSAL, T, 2, false, false, true>>});
-    // half-step stagger of the two waves of a SIMD (kernel_bf16.hip.h: attention_pass_stag)
-    v.push_back({"fp32 O, STAGGER: waves 4-7 half a step behind", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = M, .stag = 1}>>, 4});
-    v.push_back({"fp32 O, STAGGER: waves 0-3 half a step behind", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = M, .stag = 2}>>, 4});
-    v.push_back({"fp32 O, STAGGER (4-7 behind), the other engine", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = CAUSAL ? 1 : 0, .stag = 1}>>, 4});
     v.push_back({"fp32 O, the other engine", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = CAUSAL ? 1 : 0}>>, 4});
-    v.push_back({"fp32 O, STAGGER (4-7 behind), no phase priority", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = M, .prio_a = 0, .stag = 1}>>, 4});
-    v.push_back({"fp32 O, STAGGER (0-3 behind), no phase priority", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = M, .prio_a = 0, .stag = 2}>>, 4});
-    v.push_back({"STAMP fp32 O, STAGGER: waves 4-7 half a step behind", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.stamp = true, .m16 = M, .stag = 1}>>, 4});
     return v;
 }
 
