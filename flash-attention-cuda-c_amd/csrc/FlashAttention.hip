@@ -254,11 +254,14 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
             p.cpx = (p.units + 7) / 8;
             p.jpx = device_cus() / 8;   // (workgroups of one dispatch round per XCD group: what the pairing counts in)
             e = d == 64 ? launch_bf16_pair_d64(p, hp, p.jpx, plan, causal, o_dtype, st) : launch_bf16_pair_d128(p, hp, p.jpx, plan, causal, o_dtype, st);
-        } else if (hp > 0 && hp < nQ_total && causal) {   // (without the mask early_q_blocks is all or nothing)
+        } else if (hp > 0 && causal) {
+            // the mixed-precision kernel; hp = nQ_total (FA_FLAG_F16_WEIGHTS, or every row sees fewer than FA_EARLY_KEYS keys) makes it the
+            // fp16-weights kernel of the 32x32x16 engine, K by LDS-DMA: faster under the mask than the 16x16x32 one with both tiles through
+            // registers (+2.4 % at S = 4096 d = 128, +8 % at S = 2048 d = 64: profiles/r04_tune_f_fp16_everywhere_*.log)
             set_range(0, nQ_total, true);
             p.hp = hp;
             e = launch_bf16_causal_mix(p, plan, d, o_dtype, st);
-        } else if (hp > 0) {
+        } else if (hp > 0) {   // (without the mask early_q_blocks is all or nothing)
             set_range(0, hp, true);
             e = launch_bf16_p16(p, plan, causal, d, o_dtype, st);
         } else {
@@ -414,7 +417,7 @@ int flash_attention_plan_ex(int batchSize, int numHeads, int seqLenQ, int seqLen
         if (nq == 0) out->launch.grid = 0;
         else if (base.kernel_id == 1 || base.kernel_id == 2) out->launch.grid = (int)(8 * std::min<int64_t>((units + 7) / 8, fa::device_cus() / 8));
         else out->launch.grid = (int)(8 * ((units + 7) / 8));
-        if (p16) out->launch.lds_bytes = fa::bf16_p16_lds_bytes(is_causal, dHead, o_dtype);
+        if (p16) out->launch.lds_bytes = is_causal ? fa::bf16_causal_mix_lds_bytes(dHead, o_dtype) : fa::bf16_p16_lds_bytes(false, dHead, o_dtype);
     };
     fill(early, 0, hp, true);
     fill(main_, hp, nQ - hp, false);

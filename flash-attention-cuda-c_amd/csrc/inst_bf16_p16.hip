@@ -1,4 +1,5 @@
-// inst_bf16_p16.hip -- bf16 inputs with the fp16-weights precision option (FA_FLAG_F16_WEIGHTS), D = 128 / 64
+// inst_bf16_p16.hip -- bf16 inputs WITHOUT the causal mask, fp16 softmax weights on every row (FA_FLAG_F16_WEIGHTS, or seqLenK <
+// FA_EARLY_KEYS), D = 128 / 64: the 16x16x32 engine (under the mask the mixed-precision kernel of inst_bf16_mix.hip serves these calls)
 // (one translation unit of libflash_attention.so: see launchers.hip.h).
 #include "kernel_bf16.hip.h"
 #include "launchers.hip.h"
@@ -25,8 +26,8 @@ hipError_t by_out(const Params& p, const fa_launch_plan& plan, int o_dtype, hipS
 }  // namespace
 
 hipError_t launch_bf16_p16(const Params& p, const fa_launch_plan& plan, bool causal, int d, int o_dtype, hipStream_t st) {
-    if (d == 128) return causal ? by_out<128, true>(p, plan, o_dtype, st) : by_out<128, false>(p, plan, o_dtype, st);
-    return causal ? by_out<64, true>(p, plan, o_dtype, st) : by_out<64, false>(p, plan, o_dtype, st);
+    if (causal) return hipErrorInvalidValue;   // (never requested: FlashAttention.hip sends causal problems to launch_bf16_causal_mix)
+    return d == 128 ? by_out<128, false>(p, plan, o_dtype, st) : by_out<64, false>(p, plan, o_dtype, st);
 }
 
 namespace {
@@ -39,8 +40,8 @@ int lds_by_out(int o_dtype) {
 }  // namespace
 
 int bf16_p16_lds_bytes(bool causal, int d, int o_dtype) {
-    if (d == 128) return causal ? lds_by_out<128, true>(o_dtype) : lds_by_out<128, false>(o_dtype);
-    return causal ? lds_by_out<64, true>(o_dtype) : lds_by_out<64, false>(o_dtype);
+    (void)causal;   // (the carve-up does not depend on the mask)
+    return d == 128 ? lds_by_out<128, false>(o_dtype) : lds_by_out<64, false>(o_dtype);
 }
 
 }  // namespace fa

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the judged profiles of bench.py for every single-GPU workload (run from the repo root through gpurun):
-#   profiles/collect_all.sh [round tag, default r03]
+#   profiles/collect_all.sh [round tag, default r04]
 # For each of cfg2 cfg2nc cfg1 cfg3: profiles/collect.sh <tag>_<workload> <workload>, then the three summaries are gathered
 # under gpurun_out/profiles_<tag>/ with the names bench.py and DESIGN.md refer to:
 #   <tag>_kernel_stats_<workload>.csv   rocprofv3 --kernel-trace --stats of `python3 bench.py --workload <workload> ...`
@@ -8,7 +8,7 @@
 #   <tag>_sq_counters_<workload>.json   MFMA busy, clock, LDS bank conflicts
 #   <tag>_kernel_timed_<workload>.json  the same trace, averaged over the timed region only (profiles/timed_region.py)
 # Copy that directory's files into profiles/ and commit them.
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/profiles_$TAG
 mkdir -p $OUT
