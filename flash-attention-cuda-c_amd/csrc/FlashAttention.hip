@@ -261,8 +261,9 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
             set_range(0, nQ_total, true);
             p.hp = hp;
             e = launch_bf16_causal_mix(p, plan, d, o_dtype, st);
-        } else if (hp > 0) {   // (without the mask early_q_blocks is all or nothing)
+        } else if (hp > 0) {   // (without the mask early_q_blocks is all or nothing: hp = nQ_total, every unit runs with fp16 weights)
             set_range(0, hp, true);
+            p.hp = hp;
             e = launch_bf16_p16(p, plan, causal, d, o_dtype, st);
         } else {
             set_range(0, nQ_total, true);

@@ -60,7 +60,8 @@ struct WaveCompute16 {
     static constexpr int NE = 32;                  // score elements per lane per tile
     static constexpr int SPAN = SA + SB / 2;       // overall slots the exponentials are spread over
     using G = TileGeom<D, ESZ>;
-    using Stage = std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, true, false>, BufStage<D, ESZ, C::NWAVES, C::PAD, true, C::P_F16>>;
+    using Stage = std::conditional_t<C::MIX, MixStage<D, C::NWAVES, true, false>,
+                  std::conditional_t<C::DMA, DmaStage<D, C::NWAVES, true, false>, BufStage<D, ESZ, C::NWAVES, C::PAD, true, C::P_F16>>>;
     // the P.V operand type: bf16, or fp16 with the fp16-weights option (weights rounded to 11 bits instead of 8; V staged as fp16).
     // F16W is a property of the PASS, not of the kernel: the fp16-weights kernels fall back to a bf16-weights tracked pass when
     // fp16 cannot hold the unit's V (|v| > 65504 becomes inf: kernel_bf16.hip.h, run_units), so every member that touches the
@@ -91,11 +92,14 @@ struct WaveCompute16 {
     // (Later is worse -- the pieces then land after the end-of-step wait: phase A's second half -2.6 %, phase B -9 ... -13 %,
     //  profiles/r03_tune_c_dma_slots_*.log.)
     __host__ __device__ static constexpr int load_slot(int n) { return 1 + 2 * n; }
-    template <int SLOT, int N = 0>
+    template <int SLOT, bool F16W = C::P_F16, int N = 0>
     __device__ __forceinline__ void load_in_slot(Stage& st, int t_load) {
         if constexpr (N < NL) {
-            if constexpr (load_slot(N) == SLOT) st.template load<N>(t_load);
-            load_in_slot<SLOT, N + 1>(st, t_load);
+            if constexpr (load_slot(N) == SLOT) {
+                if constexpr (C::MIX) st.template load<N, F16W>(t_load);   // (MixStage: V by DMA or, fp16 units, through registers)
+                else st.template load<N>(t_load);
+            }
+            load_in_slot<SLOT, F16W, N + 1>(st, t_load);
         }
     }
 
@@ -308,7 +312,7 @@ struct WaveCompute16 {
                 constexpr int v = I - (SA - VPRE);
                 vf[v % (VPRE + 1)] = v_frag(v_cur, vbase, v / DG, v % DG);
             }
-            load_in_slot<I>(st, t_load);
+            load_in_slot<I, F16W>(st, t_load);
             if constexpr (!C::VALU_FIRST) exp_slot<I, F16W>(cur, c);
             __builtin_amdgcn_sched_barrier(0);
             slots_a<I + 1, F16W>(st, t_load, k_next, v_cur, kbase, vbase, c, cur, nxt);

@@ -82,8 +82,9 @@ struct KernelCfg {
     static constexpr bool DMA = ESZ_ == 2 && !O.pad && !O.p_f16;
     // both weight precisions in one kernel, chosen per unit (run_units); the K/V ring, the K image, the engine and the epilogue are
     // those of the LDS-DMA kernel, only V's way into LDS and the P.V operand type differ per unit
-    static constexpr bool MIX = O.mix && DMA && !M16;
-    static_assert(!O.mix || (ESZ_ == 2 && !O.pad && !O.p_f16 && O.m16 == 0), "the mixed-precision kernel is the 32x32x16 LDS-DMA kernel");
+    static constexpr bool MIX = O.mix && DMA;
+    static_assert(!O.mix || (ESZ_ == 2 && !O.pad && !O.p_f16 && O.waves == 8 && (O.m16 == 0 || O.sum_mfma == 0)),
+                  "the mixed-precision kernels are the 8-wave LDS-DMA kernels (16x16x32 engine: with fp32 row sums)");
     // fp8 inputs: K alone by LDS-DMA (V is widened to bf16 on its way into LDS and keeps the register path): HybridStageFp8
     static constexpr bool DMA_K8 = ESZ_ == 1 && D_ == 128 && !O.pad && O.waves == 8;
     static constexpr int NPRE = 4;                   // K fragments in flight ahead of their MFMA

@@ -323,11 +323,12 @@ struct DmaStage {
 // unit runs, not of the kernel: one workgroup walks units of both kinds in list order, and the next unit's tile 0 is requested in ITS form
 // while the current unit's epilogue runs.  As in HybridStageFp8 the K DMA pieces of a tile are issued before its V register loads, so that
 // hipcc's counted vmcnt for the V data never waits on a younger DMA.
-template <int D, int NWAVES>
+// V16 / KXOR: the engine's V image and K slot swap (32x32x16: false / true; 16x16x32: true / false), as in DmaStage.
+template <int D, int NWAVES, bool V16 = false, bool KXOR = true>
 struct MixStage {
     using G = TileGeom<D, 2>;
-    using Dma = DmaStage<D, NWAVES, false, true>;
-    using VPath = BufStage<D, 2, NWAVES, false, false, true>;   // (its K half stays unused)
+    using Dma = DmaStage<D, NWAVES, V16, KXOR>;
+    using VPath = BufStage<D, 2, NWAVES, false, V16, true>;     // (its K half stays unused)
     static constexpr int LOADS = Dma::LOADS;                     // pieces (DMA) or 16-byte loads per lane (registers) per tensor per tile
     static constexpr int NL = 2 * LOADS, NW = LOADS;             // NW: ds_write_b128 per lane per tile, fp16 form only
     static constexpr int KBLK = G::KBLK;

@@ -130,6 +130,8 @@ static std::vector<Variant> make_variants() {
     v.push_back({"exact row sums (the LSE instantiation)", launch_cfg<ProdCfg<D, CAUSAL, T, 2, false, false, true>>});
     v.push_back({"fp32 O, the other engine", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = CAUSAL ? 1 : 0}>>, 4});
     v.push_back({"fp32 O, fp16 weights (FA_FLAG_F16_WEIGHTS: 16x16x32 engine, K and V through registers)", launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.sum_mfma = 0, .p_f16 = true}>>, 4});
+    v.push_back({"fp32 O, fp16 weights on EVERY unit through the mixed kernel, 16x16x32 engine (K by LDS-DMA, V through registers)",
+                 [](const Params& p, int grid) { Params q = p; q.hp = p.nQ; launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.sum_mfma = 0, .mix = true}>>(q, grid); }, 4});
     v.push_back({"fp32 O, fp16 weights on EVERY unit through the mixed kernel (32x32x16 engine, K by LDS-DMA, V through registers)",
                  [](const Params& p, int grid) { Params q = p; q.hp = p.nQ; launch_cfg<KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = 0, .mix = true}>>(q, grid); }, 4});
     return v;
