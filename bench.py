@@ -242,7 +242,7 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
     def timed(n):
         """n steps between barriers; (host seconds, per-step HIP-event ms on the launch stream)"""
         sync()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         sync()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] if not dry else None
@@ -258,7 +258,7 @@ def run_workload(fa, shard, torch, dist, args, workload, world, rank, dev, steps
         if ev:
             ev[n].record()
         sync()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         sync()
         el = time.perf_counter() - t0
@@ -434,6 +434,9 @@ def main():
     from flash_attention_cuda_c_amd import shard
 
     dev = None
+    # FA_BENCH_RCCL_SINGLE=1: a ONE-rank process group over RCCL -- the N > 1 code path (init with device_id, barriers, the MAX / SUM
+    # all-reduces) on a box that has a single GPU (tests/test_bench_gpu.py); the timed region is the same
+    rccl_single = world == 1 and os.environ.get("FA_BENCH_RCCL_SINGLE") == "1" and not args.dry_run
     if args.dry_run:
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -442,10 +445,26 @@ def main():
             raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        if world > 1:
+        if world > 1 or rccl_single:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    ranks = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
+            if rccl_single:
+                import socket
+                sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(port))
+            # RCCL prints a version banner on STDOUT when its communicator comes up: keep stdout for the one JSON line (the banner goes to
+            # stderr: file descriptor 1 points at 2 while the group is created and the first collective runs)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.barrier()
+                torch.cuda.synchronize()
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+    ranks = dist.get_world_size() if dist.is_initialized() else 1
 
     line = run_workload(fa, shard, torch, dist, args, args.workload, world, rank, dev, args.steps, args.warmup, args.dry_run,
                         want_parity=world == 1 and not args.no_cpu_baseline, out_dtype=args.out_dtype)
@@ -483,7 +502,7 @@ def main():
         if not line["output_ok"]:
             rc = 3
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     return rc

@@ -22,10 +22,10 @@ def pytest_configure(config):
 DRIVER_RUNS = {}
 
 
-def _run_child(name, argv, timeout):
+def _run_child(name, argv, timeout, env=None):
     import subprocess
     try:
-        r = subprocess.run(argv, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+        r = subprocess.run(argv, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
         DRIVER_RUNS[name] = {"argv": argv, "rc": r.returncode, "stdout": r.stdout, "stderr": r.stderr}
     except Exception as e:  # noqa: BLE001 -- recorded, the test reports it
         DRIVER_RUNS[name] = {"argv": argv, "rc": None, "stdout": "", "stderr": f"{type(e).__name__}: {e}"}
@@ -51,6 +51,14 @@ def pytest_sessionstart(session):
         _run_child("fa_test", [fa_test, "--quick"], 600)
     if os.path.exists(unit):
         _run_child("unit_kernels", [unit], 300)
+    # bench.py itself (tests/test_bench_gpu.py): one rank over RCCL -- the N > 1 code path on the one GPU there is -- and the refusal of
+    # more ranks than GPUs.  Children of a process that has not touched the GPU yet, like the programs above.
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE",
+                                                              "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    bench = [sys.executable, os.path.join(ROOT, "bench.py")]
+    _run_child("bench_rccl_single", bench + ["--steps", "5", "--warmup", "2", "--no-ceiling", "--no-cfg4", "--no-bf16-out", "--cpu-budget-s", "3"], 600,
+               env=dict(clean, FA_BENCH_RCCL_SINGLE="1"))
+    _run_child("bench_gpus2", bench + ["--gpus", "2", "--steps", "2", "--warmup", "1"], 300, env=clean)
 
 
 @pytest.fixture(scope="session")
