@@ -205,7 +205,7 @@ __device__ __forceinline__ bool attention_pass(const Params& p, WaveComputeOf<C>
         if constexpr (C::STAMP) t0 = cycle_stamp();
         if (kind != 2) {
             const bool has_next = kind == 0;
-if constexpr (C::P_F16 || C::MIX)
+            if constexpr (C::P_F16 || C::MIX)
                 w.template tile_step<TRACK, F16W>(st, t + AHEAD, smem + so_wr, smem + so_nxt, smem + so_cur + KT, kbase, vbase, c, cur, nxt,
                                                   has_next, has_next && needs_mask(t + 1), (t + 1) * KVBLK, q_row0, S, lane);
             else
