@@ -104,9 +104,9 @@ struct KernelCfg {
 };
 
 // What the library launches.
-// Which engine: without the mask the kernel is power-bound and the 16x16x32 engine's cheaper MFMAs win (+0.9 ... +4.4 % over five
-// boxes); under the causal mask the idle stretches (per-unit prologue / epilogue, diagonal block) leave power to spare, cycles
-// decide, and the 32x32x16 engine's lower issue pressure wins (16x16x32: -6.8 ... +1.3 %, mean -2.3 %).  DESIGN.md section 4.
+// Which engine, by measurement on random data (the chip holds a higher clock on the 16x16x32 shape, which costs twice the MFMA issue
+// slots): without the mask 16x16x32 wins (+0.9 ... +4.4 % over five boxes), under the causal mask 32x32x16 (16x16x32: -6.8 ... +1.3 %,
+// mean -2.3 %).  What bounds either, and what recovering the seam's cycles does to the clock: DESIGN.md section 5.
 template <int D, bool CAUSAL, typename OutT, int ESZ = 2, bool STAMP = false, bool PAD = false, bool LSE = false>
 using ProdCfg = KernelCfg<D, CAUSAL, OutT, ESZ, Opt{.stamp = STAMP, .pad = PAD, .m16 = CAUSAL ? 0 : -1, .sum_mfma = LSE ? 0 : -1}>;
 
