@@ -77,7 +77,7 @@ struct WaveCompute {
     u32x4 kf[NPRE];    // K fragment window
     bf16x8 vf[VPRE + 1];
     uint32_t pw[R][16];   // P(t) as packed bf16 pairs: word 4g+w = elements 8g+2w, 8g+2w+1
-    float sum_a[R], sum_b[R], mx_a[R], mx_b[R], p_even;
+    float sum_a[R], sum_b[R], mx_a[R], mx_b[R], p_even, p_last;
     bool need;         // tracked pass: lazy-rescale decision for S(t+1)
     unsigned long long t_mid = 0, t_end = 0;   // STAMP builds only
 
@@ -256,14 +256,28 @@ struct WaveCompute {
     __device__ __forceinline__ void exp_elem(const Scores<R>& cur, float c) {
         constexpr int g = E / (8 * R), r = (E / 8) % R, j = E % 8, e = 8 * g + j;
         const float x = cur.s[r][e >> 4][e & 15];
-        const float p = fast_exp2(fmaf(x, c, -m[r]));
-        if constexpr (e & 1) {
-            sum_b[r] += p;
-            pw[r][e >> 1] = F16W ? pack_f16(p_even, p) : pack_bf16(p_even, p);
-            asm volatile("" : "+v"(sum_a[r]), "+v"(sum_b[r]));   // keep the adds in this slot (hipcc sinks them)
+        if constexpr (C::LATE_ADD) {
+            // the previous element's weight joins its sum here, in front of this element's exponential (same sums, same order)
+            if constexpr (E > 0) {
+                constexpr int rp = ((E - 1) / 8) % R, ep = 8 * ((E - 1) / (8 * R)) + (E - 1) % 8;
+                if constexpr (ep & 1) sum_b[rp] += p_last;
+                else sum_a[rp] += p_last;
+                asm volatile("" : "+v"(sum_a[rp]), "+v"(sum_b[rp]));
+            }
+            const float p = fast_exp2(fmaf(x, c, -m[r]));
+            p_last = p;
+            if constexpr (e & 1) pw[r][e >> 1] = F16W ? pack_f16(p_even, p) : pack_bf16(p_even, p);
+            else p_even = p;
         } else {
-            sum_a[r] += p;
-            p_even = p;
+            const float p = fast_exp2(fmaf(x, c, -m[r]));
+            if constexpr (e & 1) {
+                sum_b[r] += p;
+                pw[r][e >> 1] = F16W ? pack_f16(p_even, p) : pack_bf16(p_even, p);
+                asm volatile("" : "+v"(sum_a[r]), "+v"(sum_b[r]));   // keep the adds in this slot (hipcc sinks them)
+            } else {
+                sum_a[r] += p;
+                p_even = p;
+            }
         }
     }
     template <int SLOT, bool F16W = false, int E = 0>
@@ -391,6 +405,10 @@ struct WaveCompute {
         if constexpr (C::STAMP) t_mid = cycle_stamp();
         slots_b<TRACK, 0, F16W>(st, wr_slot, v_cur, vbase, c, cur, nxt);
         if constexpr (C::STAMP) t_end = cycle_stamp();
+        if constexpr (C::LATE_ADD) {   // (the tile's last weight: element NE - 1 is an odd key of the last row group)
+            static_assert(((NE - 1) % 8) & 1, "the last element feeds sum_b");
+            sum_b[((NE - 1) / 8) % R] += p_last;
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) l[r] += sum_a[r] + sum_b[r];
         // ONE rescale site: the masked (diagonal / ragged) tile only recomputes the scalar decision and

@@ -75,6 +75,10 @@ struct KernelCfg {
     // latency), -1 % on the 16x16x32 engine
     static constexpr bool VALU_FIRST = !M16;
     static constexpr bool P_F16 = M16 && O.p_f16;
+    // 32x32x16 engine: a weight joins its row sum in the slot of the NEXT weight -- no v_exp_f32 -> v_add_f32 back to back (the transcendental's
+    // result needs a wait state, which hipcc fills with an s_nop 0: ~40 per tile step).  Same sums in the same order: bitwise-equal output;
+    // +0.6 ... +1.7 % on the bf16-weights kernel, +0.3 ... +0.4 % on the mixed kernel (profiles/r04_tune_p_late_add_*.log)
+    static constexpr bool LATE_ADD = !M16;
     // K/V tiles global -> LDS by `buffer_load ... lds` (loaders.hip.h: DmaStage): no staging registers (-16 to -20 VGPRs), no
     // ds_write; +2.4 ... +4.5 % on both engines.  bf16, unpadded rows; padded / fp16-weights kernels convert or zero-fill between
     // the load and the LDS write and keep the register path.  The epilogue's LDS regions sit behind ring slot 0: the next
