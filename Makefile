@@ -17,6 +17,13 @@ tune: tests/fa_tune
 
 lib: $(LIB)
 
+# The d = 128 pair kernels run one 4-wave workgroup per CU (launch bounds 256, 1): hipcc would then place the MFMA accumulators in the
+# accumulation registers and pay a v_accvgpr_read for every score the softmax touches (-6 ... -11 %, profiles/r04_tune_q_*); with the
+# MFMAs in VGPR form the second half of the register file only takes what would otherwise spill
+MFMA_VGPR := -mllvm -amdgpu-mfma-vgpr-form=1
+build/obj/inst_bf16_pair_d128.o: HIPFLAGS += $(MFMA_VGPR)
+tests/fa_tune tests/fa_tune_c128: HIPFLAGS += $(MFMA_VGPR)
+
 build/obj/%.o: $(PKG)/csrc/%.hip $(KHDR)
 	@mkdir -p build/obj
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<

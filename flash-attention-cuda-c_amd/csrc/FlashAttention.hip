@@ -253,6 +253,7 @@ static int run(const void* Q, const void* K, const void* V, void* O, float* lse,
             p.units = B * H * nQ_total;
             p.cpx = (p.units + 7) / 8;
             p.jpx = device_cus() / 8;   // (workgroups of one dispatch round per XCD group: what the pairing counts in)
+            p.hp = hp;                  // (d = 128: one mixed-precision configuration, the unit's block says which precision)
             e = d == 64 ? launch_bf16_pair_d64(p, hp, p.jpx, plan, causal, o_dtype, st) : launch_bf16_pair_d128(p, hp, p.jpx, plan, causal, o_dtype, st);
         } else if (hp > 0 && causal) {
             // the mixed-precision kernel; hp = nQ_total (FA_FLAG_F16_WEIGHTS, or every row sees fewer than FA_EARLY_KEYS keys) makes it the

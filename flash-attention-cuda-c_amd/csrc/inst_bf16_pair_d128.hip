@@ -7,12 +7,14 @@
 namespace fa {
 namespace {
 
-// bf16 weights: the engine of the persistent kernels (32x32x16 under the mask, 16x16x32 without; LDS-DMA staging).  Without the mask the row
-// sums are the exact fp32 ones (the persistent kernels' LSE instantiation) whether or not the call asks for the LSE: one instantiation
+// ONE configuration for both weight precisions: the four-wave form of the persistent kernels' mixed-precision kernel (KernelCfg::MIX) on their
+// engine (32x32x16 under the mask, 16x16x32 without) -- K by LDS-DMA, V by LDS-DMA (bf16 weights) or as fp16 through registers (the blocks
+// qb < Params::hp), exact fp32 row sums whether or not the call asks for the LSE.  (Until round 4 the fp16 blocks ran the register-staged
+// 16x16x32 kernel, whose 32 staging registers at four waves spilled 31 VGPRs into its tile loop.)
 template <bool CAUSAL, typename OutT>
-using PairA = KernelCfg<128, CAUSAL, OutT, 2, Opt{.m16 = CAUSAL ? 0 : -1, .sum_mfma = 0, .waves = 4}>;
+using PairA = KernelCfg<128, CAUSAL, OutT, 2, Opt{.m16 = CAUSAL ? 0 : -1, .sum_mfma = 0, .waves = 4, .mix = true}>;
 template <bool CAUSAL, typename OutT>
-using PairB = KernelCfg<128, CAUSAL, OutT, 2, Opt{.sum_mfma = 0, .waves = 4, .p_f16 = true}>;      // fp16 weights
+using PairB = PairA<CAUSAL, OutT>;
 
 template <bool CAUSAL, typename OutT>
 constexpr int pair_lds() {

@@ -87,8 +87,8 @@ struct KernelCfg {
     // both weight precisions in one kernel, chosen per unit (run_units); the K/V ring, the K image, the engine and the epilogue are
     // those of the LDS-DMA kernel, only V's way into LDS and the P.V operand type differ per unit
     static constexpr bool MIX = O.mix && DMA;
-    static_assert(!O.mix || (ESZ_ == 2 && !O.pad && !O.p_f16 && O.waves == 8 && (O.m16 == 0 || O.sum_mfma == 0)),
-                  "the mixed-precision kernels are the 8-wave LDS-DMA kernels (16x16x32 engine: with fp32 row sums)");
+    static_assert(!O.mix || (ESZ_ == 2 && !O.pad && !O.p_f16 && (O.m16 == 0 || O.sum_mfma == 0)),
+                  "the mixed-precision kernels are the LDS-DMA kernels (16x16x32 engine: with fp32 row sums)");
     // fp8 inputs: K alone by LDS-DMA (V is widened to bf16 on its way into LDS and keeps the register path): HybridStageFp8
     static constexpr bool DMA_K8 = ESZ_ == 1 && D_ == 128 && !O.pad && O.waves == 8;
     static constexpr int NPRE = 4;                   // K fragments in flight ahead of their MFMA
@@ -480,8 +480,9 @@ __global__ __launch_bounds__(64 * C::NWAVES, 2) void fwd_mfma_kernel(const Param
 // (the rows that see fewer than FA_EARLY_KEYS keys) run configuration CB, the others CA (include/flash_attention.h, "Precision ...").
 // Without the mask the units are equal and the order means nothing: the kernel is then used only where 256-row units would leave half of
 // the CUs idle (one unit per workgroup, one dispatch round), and hp is all or nothing.
+// (where the LDS leaves room for one workgroup per CU only, its four waves have a SIMD each: the whole 512-register file)
 template <class CA, class CB>
-__global__ __launch_bounds__(64 * CA::NWAVES, 2) void fwd_mfma_pair_kernel(const Params p, const int hp, const int jpx) {
+__global__ __launch_bounds__(64 * CA::NWAVES, (CA::LDS_BYTES > 81920 || CB::LDS_BYTES > 81920) ? 1 : 2) void fwd_mfma_pair_kernel(const Params p, const int hp, const int jpx) {
     static_assert(CA::NWAVES == 4 && CB::NWAVES == 4 && CA::CAUSAL == CB::CAUSAL, "one workgroup shape, one mask");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
@@ -493,8 +494,12 @@ __global__ __launch_bounds__(64 * CA::NWAVES, 2) void fwd_mfma_pair_kernel(const
     if (idx >= n || (s >= jpx && idx < jpx)) return;
     const int blk = idx / nh;
     const UnitList one{p.nQ, p.nQ - 1 - blk, h0 + (idx - blk * nh), 0, 0};
-    if (one.qb0 < hp) run_units<CB, Kind::ONE>(p, one, (lds_ptr)smem_raw);
-    else run_units<CA, Kind::ONE>(p, one, (lds_ptr)smem_raw);
+    if constexpr (std::is_same_v<CA, CB>) {   // a mixed-precision configuration: the unit's block says which (Params::hp == hp)
+        run_units<CA, Kind::ONE>(p, one, (lds_ptr)smem_raw);
+    } else {
+        if (one.qb0 < hp) run_units<CB, Kind::ONE>(p, one, (lds_ptr)smem_raw);
+        else run_units<CA, Kind::ONE>(p, one, (lds_ptr)smem_raw);
+    }
 }
 
 }  // namespace fa

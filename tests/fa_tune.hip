@@ -105,8 +105,10 @@ static std::vector<Variant> make_variants() {
     {
         // small problems: 128-row units, one per workgroup of four waves (fwd_mfma_pair_kernel; causal d = 64: two workgroups per CU, paired)
         auto pair = [](const Params& p, unsigned flags) {
-            using CA = KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = CAUSAL ? 0 : -1, .sum_mfma = 0, .waves = 4}>;
-            using CB = KernelCfg<D, CAUSAL, float, 2, Opt{.sum_mfma = 0, .waves = 4, .p_f16 = true}>;
+            // (the library's configurations: inst_bf16_pair_d64.hip; inst_bf16_pair_d128.hip: one mixed-precision configuration for both)
+            using CA = std::conditional_t<D == 128, KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = CAUSAL ? 0 : -1, .sum_mfma = 0, .waves = 4, .mix = true}>,
+                                          KernelCfg<D, CAUSAL, float, 2, Opt{.m16 = CAUSAL ? 0 : -1, .sum_mfma = 0, .waves = 4}>>;
+            using CB = std::conditional_t<D == 128, CA, KernelCfg<D, CAUSAL, float, 2, Opt{.sum_mfma = 0, .waves = 4, .p_f16 = true}>>;
             constexpr int lds = CA::LDS_BYTES > CB::LDS_BYTES ? CA::LDS_BYTES : CB::LDS_BYTES;
             static bool once = [] {
                 HIP_CHECK(hipFuncSetAttribute((const void*)fwd_mfma_pair_kernel<CA, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -116,6 +118,7 @@ static std::vector<Variant> make_variants() {
             Params q = p;
             q.nQ = (p.S + 127) / 128;
             const int hp = (flags == 2 || !CAUSAL) ? 0 : std::min(q.nQ, 1024 / 128);
+            q.hp = hp;
             const int jpx = g_cus / 8;
             const int per_group = ((p.B * p.H + 7) / 8) * q.nQ;
             hipLaunchKernelGGL((fwd_mfma_pair_kernel<CA, CB>), dim3(8 * (per_group <= jpx ? per_group : 2 * jpx)), dim3(256), lds, nullptr, q, hp, jpx);
