@@ -3,6 +3,7 @@
 // Each "slot" = 1 v_mfma_f32_32x32x16_bf16 + a configurable number of VALU / transcendental / LDS instructions.
 // Prints cycles per MFMA per SIMD (32 = pipe saturated), the aggregate TFLOP/s and the clock the chip held.
 //   simd_mix [workgroups] [iterations]     table of instruction mixes (1 workgroup = one CU; 256 = whole chip)
+//   simd_mix --levers [iterations]         whole chip, random operands: the attention mix with one ingredient removed at a time
 //   simd_mix --ceiling [iterations]        one JSON line: whole-chip throughput with RANDOM bf16 operands for
 //                                          (a) MFMA only and (b) MFMA + the softmax VALU mix + the K/V^T LDS-read
 //                                          mix of the attention kernel.  On MI355X these are set by the power
@@ -182,6 +183,28 @@ int main(int argc, char** argv) {
         printf("{\"mfma_only_random_bf16_tflops\": %.1f, \"mfma_only_clock_ghz\": %.3f, \"mfma_only_pipe_busy\": %.3f, "
                "\"attention_mix_random_bf16_tflops\": %.1f, \"attention_mix_clock_ghz\": %.3f, \"attention_mix_pipe_busy\": %.3f, "
                "\"workgroups\": %d, \"mfma_per_wave\": %d}\n", a, ac, ap, g_last_tflops, g_last_clock, g_last_pipe, g_grid, g_rep * SLOTS);
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "--levers") {
+        // What each ENERGY lever is worth on this device: whole chip, random bf16 operands, the attention kernel's instruction mix with one
+        // ingredient taken out at a time (the chip is power-limited under these streams: TFLOP/s follows the clock it holds).
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        g_grid = cus; g_rep = argc > 2 ? atoi(argv[2]) : 3000;
+        printf("grid = %d workgroups, %d iterations of %d slots, RANDOM bf16 operands\n", g_grid, g_rep, SLOTS);
+        //   fma exp add cvt b128 tr  chain  random
+        run<0, 0, 0, 0, 0, 0, false, true>("MFMA only", d);
+        run<16, 16, 16, 8, 8, 16, false, true>("attention mix: fma + exp + add + 0.5 cvt, 0.5 b128 + 1 tr64", d);
+        run<16, 16, 0, 8, 8, 16, false, true>("  without the row-sum add", d);
+        run<0, 16, 16, 8, 8, 16, false, true>("  without the fma (operand prescaled)", d);
+        run<16, 16, 16, 8, 4, 8, false, true>("  with half the LDS reads (64 rows per wave)", d);
+        run<16, 16, 0, 8, 4, 8, false, true>("  without the add, half the LDS reads", d);
+        run<0, 16, 0, 8, 4, 8, false, true>("  without add and fma, half the LDS reads", d);
+        run<16, 16, 16, 8, 0, 0, false, true>("  without any LDS read", d);
+        run<0, 0, 0, 0, 8, 16, false, true>("  LDS reads only (no softmax instructions)", d);
+        run<16, 16, 16, 8, 8, 16, false, true, 0, false, true>("attention mix on 16x16x32 MFMAs (two per slot)", d);
+        run<16, 16, 0, 8, 8, 16, false, true, 0, false, true>("  without the row-sum add (16x16x32)", d);
+        run<16, 16, 16, 8, 4, 8, false, true, 0, false, true>("  with half the LDS reads (16x16x32)", d);
         return 0;
     }
     if (argc > 1) g_grid = atoi(argv[1]);
